@@ -1,0 +1,115 @@
+"""ctypes binding of libcsmpn_hip.so (C-ABI declared in include/csmpn_hip.h).
+
+The library is the product: there is no CPU or PyTorch-eager fallback. If it is
+missing the import fails loudly with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsmpn_hip.so")
+
+MAX_BLOCKS = 4
+
+# every symbol include/csmpn_hip.h declares
+EXPORTS = (
+    "csmpn_metric_supported",
+    "csmpn_algebra_tables",
+    "csmpn_geometric_product_forward",
+    "csmpn_geometric_product_backward",
+    "csmpn_cemlp_workspace_bytes",
+    "csmpn_cemlp_forward",
+    "csmpn_cemlp_backward",
+    "csmpn_csr_build",
+    "csmpn_egcl_edge_forward",
+    "csmpn_egcl_edge_backward",
+    "csmpn_egcl_node_forward",
+    "csmpn_egcl_node_backward",
+    "csmpn_last_error",
+    "csmpn_abi_version",
+    "csmpn_build_target",
+)
+
+PARAM_FIELDS = ("lin_w", "lin_b", "silu_a", "silu_b", "gp_w", "norm_a", "right_w", "left_w", "left_b", "ln_a")
+
+
+class BlockParams(C.Structure):
+    _fields_ = [
+        ("in_features", C.c_int32),
+        ("out_features", C.c_int32),
+        ("lin_subspaces", C.c_int32),
+        ("reserved", C.c_int32),
+    ] + [(name, C.c_void_p) for name in PARAM_FIELDS]
+
+
+class BlockGrads(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in PARAM_FIELDS]
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found. This package has no CPU/eager fallback: build the HIP "
+            f"library first (python -c 'import __graft_entry__ as g; g.build()' or "
+            f"make -C {os.path.join(os.path.dirname(_HERE), 'csrc')})."
+        )
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    fp = C.POINTER(C.c_float)
+    bp, bg = C.POINTER(BlockParams), C.POINTER(BlockGrads)
+
+    def sig(name, res, args):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+    sig("csmpn_metric_supported", C.c_int, [fp, C.c_int])
+    sig("csmpn_algebra_tables", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, vp])
+    sig("csmpn_geometric_product_forward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, vp])
+    sig("csmpn_geometric_product_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, i64, vp])
+    sig("csmpn_cemlp_workspace_bytes", sz, [C.c_int, bp, C.c_int])
+    sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, sz, vp])
+    sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, sz, vp])
+    sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp])
+    sig("csmpn_egcl_edge_forward", C.c_int,
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, sz, vp])
+    sig("csmpn_egcl_edge_backward", C.c_int,
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, sz, vp])
+    sig("csmpn_egcl_node_forward", C.c_int,
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, sz, vp])
+    sig("csmpn_egcl_node_backward", C.c_int,
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, sz, vp])
+    sig("csmpn_last_error", C.c_char_p, [])
+    sig("csmpn_abi_version", C.c_int, [])
+    sig("csmpn_build_target", C.c_char_p, [])
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+class CsmpnError(RuntimeError):
+    pass
+
+
+def check(rc: int):
+    if rc != 0:
+        raise CsmpnError(f"csmpn_hip error {rc}: {lib().csmpn_last_error().decode()}")
+
+
+def metric_array(metric):
+    arr = (C.c_float * len(metric))(*[float(m) for m in metric])
+    return arr

@@ -1,0 +1,353 @@
+"""torch.autograd Functions over the C-ABI (include/csmpn_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams and records the
+autograd graph; every forward and backward of the path runs in the HIP library.
+There is no eager fallback: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import native
+from .native import BlockGrads, BlockParams, PARAM_FIELDS, check
+
+NP = len(PARAM_FIELDS)  # parameter slots per CEMLP block
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} is on {t.device}: the csmpn HIP path runs on MI355X only and has no CPU fallback "
+            f"(the CPU restatement lives in oracle/ and is test infrastructure)."
+        )
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{what} must be float32, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class CemlpBinding:
+    """ctypes view of one CEMLP's parameters, cached across calls.
+
+    `specs` is a list (one per block) of dicts with in_features, out_features,
+    lin_subspaces. Parameters arrive per call as a flat list of NP tensors per
+    block in PARAM_FIELDS order (None for an absent MVLinear bias).
+    """
+
+    def __init__(self, metric: Sequence[float], specs: List[dict]):
+        self.metric = tuple(float(m) for m in metric)
+        self.n = len(self.metric)
+        self.D = 1 << self.n
+        self.metric_arr = native.metric_array(self.metric)
+        self.nblk = len(specs)
+        if not 1 <= self.nblk <= native.MAX_BLOCKS:
+            raise native.CsmpnError(f"CEMLP with {self.nblk} blocks not supported (1..{native.MAX_BLOCKS})")
+        self.params = (BlockParams * self.nblk)()
+        self.grads = (BlockGrads * self.nblk)()
+        for k, s in enumerate(specs):
+            self.params[k].in_features = int(s["in_features"])
+            self.params[k].out_features = int(s["out_features"])
+            self.params[k].lin_subspaces = 1 if s.get("lin_subspaces", True) else 0
+        self.in_features = int(specs[0]["in_features"])
+        self.out_features = int(specs[-1]["out_features"])
+        self._key = None
+        self._grad_layout = None
+        self._ws_bytes = None
+
+    def supported(self) -> bool:
+        return bool(native.lib().csmpn_metric_supported(self.metric_arr, self.n))
+
+    def bind(self, params: Sequence[Optional[torch.Tensor]]):
+        assert len(params) == NP * self.nblk
+        key = tuple(_ptr(p) for p in params)
+        if key != self._key:
+            for k in range(self.nblk):
+                blk = self.params[k]
+                for j, name in enumerate(PARAM_FIELDS):
+                    p = params[k * NP + j]
+                    if p is not None and not p.is_contiguous():
+                        raise RuntimeError(f"parameter {name} of block {k} must be contiguous")
+                    setattr(blk, name, key[k * NP + j])
+            self._key = key
+            self._grad_layout = None
+        if self._ws_bytes is None:
+            self._ws_bytes = int(native.lib().csmpn_cemlp_workspace_bytes(self.n, self.params, self.nblk))
+
+    def workspace(self, device) -> torch.Tensor:
+        return torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=device)
+
+    def new_grads(self, params: Sequence[Optional[torch.Tensor]], device):
+        """One zeroed flat buffer for all parameter gradients (a single memset);
+        returns (flat, views) with views[i] shaped like params[i]."""
+        if self._grad_layout is None:
+            offs, total = [], 0
+            for p in params:
+                if p is None:
+                    offs.append(None)
+                else:
+                    offs.append((total, p.numel(), tuple(p.shape)))
+                    total += (p.numel() + 3) // 4 * 4
+            self._grad_layout = (offs, total)
+        offs, total = self._grad_layout
+        flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+        base = flat.data_ptr()
+        views = []
+        for k in range(self.nblk):
+            g = self.grads[k]
+            for j, name in enumerate(PARAM_FIELDS):
+                o = offs[k * NP + j]
+                if o is None:
+                    setattr(g, name, None)
+                    views.append(None)
+                else:
+                    setattr(g, name, base + 4 * o[0])
+                    views.append(flat[o[0]:o[0] + o[1]].view(o[2]))
+        return flat, views
+
+
+# --------------------------------------------------------------------------------- CEMLP
+
+
+class _CemlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, binding: CemlpBinding, *params):
+        _require_device(x, "CEMLP input")
+        if x.dim() != 3 or x.shape[1] != binding.in_features or x.shape[2] != binding.D:
+            raise RuntimeError(f"CEMLP input must be [rows, {binding.in_features}, {binding.D}], got {tuple(x.shape)}")
+        x = x.contiguous()
+        binding.bind(params)
+        rows = x.shape[0]
+        y = torch.empty(rows, binding.out_features, binding.D, dtype=torch.float32, device=x.device)
+        ws = binding.workspace(x.device)
+        check(native.lib().csmpn_cemlp_forward(binding.metric_arr, binding.n, binding.params, binding.nblk,
+                                               x.data_ptr(), rows, y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               _stream(x.device)))
+        ctx.binding = binding
+        ctx.save_for_backward(x, *[p for p in params if p is not None])
+        ctx.mask = [p is not None for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        binding = ctx.binding
+        x, *present = ctx.saved_tensors
+        it = iter(present)
+        params = [next(it) if m else None for m in ctx.mask]
+        gy = gy.contiguous()
+        binding.bind(params)
+        flat, views = binding.new_grads(params, x.device)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = binding.workspace(x.device)
+        check(native.lib().csmpn_cemlp_backward(binding.metric_arr, binding.n, binding.params, binding.grads,
+                                                binding.nblk, x.data_ptr(), gy.data_ptr(), x.shape[0], _ptr(gx),
+                                                ws.data_ptr(), ws.numel(), _stream(x.device)))
+        return (gx, None, *views)
+
+
+def cemlp_apply(x, binding: CemlpBinding, params):
+    return _CemlpFn.apply(x, binding, *params)
+
+
+# --------------------------------------------------------------------------------- CSR
+
+
+class Csr:
+    """Target-sorted adjacency of one complex (built once, reused by every layer and step)."""
+
+    __slots__ = ("perm", "src", "dst", "deg", "row_ptr", "n_edges", "n_nodes", "_scratch")
+
+    def __init__(self, edge_index: torch.Tensor, n_nodes: int):
+        if not edge_index.is_cuda:
+            raise RuntimeError("edge_index must live on the GPU (no CPU fallback)")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError("edge_index must be int64 [2, E]")
+        ei = edge_index.contiguous()
+        dev = ei.device
+        E = ei.shape[1]
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.n_edges, self.n_nodes = E, n_nodes
+        self.perm = torch.empty(max(E, 1), **i32)
+        self.src = torch.empty(max(E, 1), **i32)
+        self.dst = torch.empty(max(E, 1), **i32)
+        self.deg = torch.empty(n_nodes, **i32)
+        self.row_ptr = torch.empty(n_nodes + 1, **i32)
+        self._scratch = torch.empty(n_nodes + 1, **i32)
+        check(native.lib().csmpn_csr_build(ei.data_ptr(), E, n_nodes, self.perm.data_ptr(), self.src.data_ptr(),
+                                           self.dst.data_ptr(), self.deg.data_ptr(), self.row_ptr.data_ptr(),
+                                           self._scratch.data_ptr(), _stream(dev)))
+
+
+def get_csr(edge_index: torch.Tensor, n_nodes: int) -> Csr:
+    """CSR cached on the edge_index tensor object itself (complexes are static:
+    every layer of a model and every epoch pass the same tensor)."""
+    cached = getattr(edge_index, "_csmpn_csr", None)
+    if cached is not None and cached[0] == edge_index._version and cached[1].n_nodes == n_nodes:
+        return cached[1]
+    csr = Csr(edge_index, n_nodes)
+    try:
+        edge_index._csmpn_csr = (edge_index._version, csr)
+    except Exception:
+        pass
+    return csr
+
+
+# --------------------------------------------------------------------------------- EGCL
+
+
+class EgclSpec:
+    """Static description of one EGCL layer for the autograd Function."""
+
+    def __init__(self, edge: CemlpBinding, node: CemlpBinding, channels: int, out_channels: int,
+                 edge_attr_channels: int, node_attr_channels: int, aggr: str, residual: bool):
+        if aggr not in ("mean", "sum", "add"):
+            raise native.CsmpnError(f"aggr={aggr!r} not supported by the HIP path (mean | sum | add)")
+        self.edge, self.node = edge, node
+        self.C, self.O = channels, out_channels
+        self.A, self.T = edge_attr_channels, node_attr_channels
+        self.mean = 1 if aggr == "mean" else 0
+        self.residual = 1 if residual else 0
+
+
+class _EgclFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, edge_attr, node_attr, spec: EgclSpec, csr: Csr, *params):
+        _require_device(h, "EGCL input h")
+        lib = native.lib()
+        e, nd = spec.edge, spec.node
+        N, D = h.shape[0], e.D
+        if h.dim() != 3 or h.shape[1] != spec.C or h.shape[2] != D:
+            raise RuntimeError(f"h must be [N, {spec.C}, {D}], got {tuple(h.shape)}")
+        if (edge_attr is None) != (spec.A == 0) or (node_attr is None) != (spec.T == 0):
+            raise RuntimeError("edge_attr/node_attr presence does not match edge_attr_features/node_attr_features")
+        h = h.contiguous()
+        if edge_attr is not None:
+            _require_device(edge_attr, "edge_attr")
+            edge_attr = edge_attr.contiguous()
+            if tuple(edge_attr.shape) != (csr.n_edges, spec.A, D):
+                raise RuntimeError(f"edge_attr must be [{csr.n_edges}, {spec.A}, {D}], got {tuple(edge_attr.shape)}")
+        if node_attr is not None:
+            _require_device(node_attr, "node_attr")
+            node_attr = node_attr.contiguous()
+            if tuple(node_attr.shape) != (N, spec.T, D):
+                raise RuntimeError(f"node_attr must be [{N}, {spec.T}, {D}], got {tuple(node_attr.shape)}")
+        ne = e.nblk * NP
+        pe, pn = params[:ne], params[ne:]
+        e.bind(pe)
+        nd.bind(pn)
+        st = _stream(h.device)
+        agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
+        ws = e.workspace(h.device)
+        check(lib.csmpn_egcl_edge_forward(e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C,
+                                          _ptr(edge_attr), spec.A, csr.perm.data_ptr(), csr.src.data_ptr(),
+                                          csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), st))
+        out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
+        ws2 = nd.workspace(h.device)
+        check(lib.csmpn_egcl_node_forward(nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C,
+                                          agg.data_ptr(), spec.O, _ptr(node_attr), spec.T, csr.deg.data_ptr(),
+                                          spec.mean, spec.residual, N, out.data_ptr(), ws2.data_ptr(), ws2.numel(), st))
+        ctx.spec, ctx.csr = spec, csr
+        ctx.has_ea, ctx.has_na = edge_attr is not None, node_attr is not None
+        ctx.mask = [p is not None for p in params]
+        saved = [h, agg]
+        if ctx.has_ea:
+            saved.append(edge_attr)
+        if ctx.has_na:
+            saved.append(node_attr)
+        ctx.save_for_backward(*saved, *[p for p in params if p is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = native.lib()
+        spec, csr = ctx.spec, ctx.csr
+        e, nd = spec.edge, spec.node
+        saved = list(ctx.saved_tensors)
+        h, agg = saved[0], saved[1]
+        pos = 2
+        edge_attr = node_attr = None
+        if ctx.has_ea:
+            edge_attr = saved[pos]; pos += 1
+        if ctx.has_na:
+            node_attr = saved[pos]; pos += 1
+        it = iter(saved[pos:])
+        params = [next(it) if m else None for m in ctx.mask]
+        ne = e.nblk * NP
+        pe, pn = params[:ne], params[ne:]
+        e.bind(pe)
+        nd.bind(pn)
+        N, D = h.shape[0], e.D
+        dev = h.device
+        st = _stream(dev)
+        gout = gout.contiguous()
+        # one zeroed buffer for all parameter gradients of both CEMLPs
+        flat_e, views_e = e.new_grads(pe, dev)
+        flat_n, views_n = nd.new_grads(pn, dev)
+        gh = torch.empty_like(h)
+        g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
+        g_na = torch.empty_like(node_attr) if (ctx.has_na and ctx.needs_input_grad[2]) else None
+        g_ea = torch.empty_like(edge_attr) if (ctx.has_ea and ctx.needs_input_grad[1]) else None
+        ws2 = nd.workspace(dev)
+        check(lib.csmpn_egcl_node_backward(nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C,
+                                           agg.data_ptr(), spec.O, _ptr(node_attr), spec.T, csr.deg.data_ptr(),
+                                           spec.mean, spec.residual, N, gout.data_ptr(), gh.data_ptr(),
+                                           g_agg.data_ptr(), _ptr(g_na), ws2.data_ptr(), ws2.numel(), st))
+        ws = e.workspace(dev)
+        check(lib.csmpn_egcl_edge_backward(e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C,
+                                           _ptr(edge_attr), spec.A, csr.perm.data_ptr(), csr.src.data_ptr(),
+                                           csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(), gh.data_ptr(),
+                                           _ptr(g_ea), ws.data_ptr(), ws.numel(), st))
+        return (gh, g_ea, g_na, None, None, *views_e, *views_n)
+
+
+def egcl_apply(h, edge_attr, node_attr, spec: EgclSpec, csr: Csr, params):
+    return _EgclFn.apply(h, edge_attr, node_attr, spec, csr, *params)
+
+
+# --------------------------------------------------------------------------------- geometric product
+
+
+class _GpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, metric):
+        _require_device(a, "geometric_product operand")
+        _require_device(b, "geometric_product operand")
+        shape = torch.broadcast_shapes(a.shape, b.shape)
+        a2 = a.expand(shape).contiguous()
+        b2 = b.expand(shape).contiguous()
+        n = len(metric)
+        D = 1 << n
+        rows = a2.numel() // D
+        out = torch.empty_like(a2)
+        check(native.lib().csmpn_geometric_product_forward(native.metric_array(metric), n, a2.data_ptr(),
+                                                           b2.data_ptr(), out.data_ptr(), rows, _stream(a.device)))
+        ctx.save_for_backward(a2, b2)
+        ctx.metric, ctx.shapes = metric, (a.shape, b.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        a2, b2 = ctx.saved_tensors
+        metric = ctx.metric
+        n = len(metric)
+        D = 1 << n
+        gout = gout.contiguous()
+        ga, gb = torch.zeros_like(a2), torch.zeros_like(b2)
+        check(native.lib().csmpn_geometric_product_backward(native.metric_array(metric), n, a2.data_ptr(),
+                                                            b2.data_ptr(), gout.data_ptr(), ga.data_ptr(),
+                                                            gb.data_ptr(), a2.numel() // D, _stream(a2.device)))
+        sa, sb = ctx.shapes
+        return ga.sum_to_size(sa), gb.sum_to_size(sb), None
+
+
+def geometric_product_apply(a, b, metric):
+    return _GpFn.apply(a, b, tuple(float(m) for m in metric))

@@ -1,0 +1,571 @@
+// C-ABI of the library (declared in include/csmpn_hip.h): host-side table
+// construction, launch planning, weight packing, CSR build and dispatch to the
+// per-algebra kernel instantiations.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/csmpn_hip.h"
+#include "cemlp_kernel.hpp"
+#include "launch.hpp"
+
+using namespace csmpn;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(CSMPN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int rup(int a, int b) { return cdiv(a, b) * b; }
+
+// ----------------------------------------------------------------------------- algebra id
+enum AlgId { ALG_NONE = -1, ALG_N2, ALG_N3, ALG_N4, ALG_N5, ALG_N5M, ALG_N4M };
+
+AlgId alg_id(const float* metric, int n) {
+    if (!metric || n < 2 || n > 5) return ALG_NONE;
+    unsigned neg = 0;
+    for (int i = 0; i < n; ++i) {
+        if (metric[i] == 1.0f) continue;
+        if (metric[i] == -1.0f) { neg |= 1u << i; continue; }
+        return ALG_NONE;
+    }
+    if (n == 2 && neg == 0) return ALG_N2;
+    if (n == 3 && neg == 0) return ALG_N3;
+    if (n == 4 && neg == 0) return ALG_N4;
+    if (n == 5 && neg == 0) return ALG_N5;
+    if (n == 5 && neg == 0x10u) return ALG_N5M;
+    if (n == 4 && neg == 0x8u) return ALG_N4M;
+    return ALG_NONE;
+}
+
+int n_paths(AlgId id) {
+    switch (id) {
+        case ALG_N2: return Alg<2, 0u>::P;
+        case ALG_N3: return Alg<3, 0u>::P;
+        case ALG_N4: return Alg<4, 0u>::P;
+        case ALG_N5: return Alg<5, 0u>::P;
+        case ALG_N5M: return Alg<5, 0x10u>::P;
+        case ALG_N4M: return Alg<4, 0x8u>::P;
+        default: return 0;
+    }
+}
+
+hipError_t launch_cemlp(AlgId id, int mode, bool multi, bool bwd, unsigned grid, unsigned block, size_t lds,
+                        hipStream_t st, const DevCemlp& C, const RowIO& io) {
+    switch (id) {
+        case ALG_N2: return launch_cemlp_n2(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N3: return launch_cemlp_n3(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N4: return launch_cemlp_n4(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N5: return launch_cemlp_n5(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N5M: return launch_cemlp_n5m(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N4M: return launch_cemlp_n4m(mode, multi, bwd, grid, block, lds, st, C, io);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_gp(AlgId id, bool bwd, const float* a, const float* b, const float* gout, float* out, float* ga,
+                     float* gb, long rows, hipStream_t st) {
+    switch (id) {
+        case ALG_N2: return launch_gp_n2(bwd, a, b, gout, out, ga, gb, rows, st);
+        case ALG_N3: return launch_gp_n3(bwd, a, b, gout, out, ga, gb, rows, st);
+        case ALG_N4: return launch_gp_n4(bwd, a, b, gout, out, ga, gb, rows, st);
+        case ALG_N5: return launch_gp_n5(bwd, a, b, gout, out, ga, gb, rows, st);
+        case ALG_N5M: return launch_gp_n5m(bwd, a, b, gout, out, ga, gb, rows, st);
+        case ALG_N4M: return launch_gp_n4m(bwd, a, b, gout, out, ga, gb, rows, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ----------------------------------------------------------------------------- weight packing kernel
+__global__ void pack_weights_kernel(const PackDesc P) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= P.total) return;
+    int s = 0;
+    while (e >= P.seg[s].count) { e -= P.seg[s].count; ++s; }
+    const PackSeg& S = P.seg[s];
+    const int lane = e & 63;
+    int rest = e >> 6;
+    // fragment order [n-tile][grade][k-block][lane]
+    const int kk = rest % S.KK; rest /= S.KK;
+    const int g = rest % P.G; rest /= P.G;
+    const int nt = rest;
+    const int n = 16 * nt + (lane & 15);
+    f4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = 16 * kk + 4 * (lane >> 4) + r;
+        const int o = S.transposed ? k : n, i = S.transposed ? n : k;
+        float val = 0.f;
+        if (o < S.O && i < S.I) val = S.has_grades ? S.w[((size_t)o * S.I + i) * P.G + g] : S.w[(size_t)o * S.I + i];
+        v[r] = val;
+    }
+    S.dst[e] = v;
+}
+
+
+// ----------------------------------------------------------------------------- planning
+struct Plan {
+    DevCemlp C;
+    PackDesc P;
+    size_t pack_f4;       // f4 elements of packed weights
+    unsigned threads;
+    size_t lds_bytes;
+    unsigned grid_cap;    // workgroups that fit on the chip at once
+    bool multi;
+};
+
+size_t packed_f4_count(int G, const csmpn_block_params* blocks, int nblk) {
+    size_t tot = 0;
+    for (int k = 0; k < nblk; ++k) {
+        const int I = blocks[k].in_features, O = blocks[k].out_features;
+        const size_t KKi = cdiv(I, 16), KKo = cdiv(O, 16);
+        tot += 2 * (size_t)G * KKo * KKi * 64;       // W1 forward + transposed
+        tot += 4 * (size_t)G * KKo * KKo * 64;       // WR, WL forward + transposed
+    }
+    return tot;
+}
+
+int mirror_floats_of(int I, int O, int G, int P, bool sub) {
+    return (sub ? G : 1) * O * I + 2 * G * O * O + 3 * O + 3 * O * G + O * P;
+}
+
+// mode/bwd decide the LDS footprint. stage_rowlen: dense staging row length needed in buf_g (edge forward).
+int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads, int nblk,
+              void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, Plan& plan) {
+    if (nblk < 1 || nblk > CSMPN_MAX_BLOCKS) return fail(CSMPN_ERR_INVALID, "n_blocks=%d not in 1..%d", nblk, CSMPN_MAX_BLOCKS);
+    const int D = 1 << n, G = n + 1, P = n_paths(id);
+    memset(&plan, 0, sizeof(plan));
+    DevCemlp& C = plan.C;
+    C.nblk = nblk;
+    int maxO = 0, maxCPo = 0;
+    for (int k = 0; k < nblk; ++k) {
+        const csmpn_block_params& b = blocks[k];
+        if (b.in_features < 1 || b.out_features < 1) return fail(CSMPN_ERR_INVALID, "block %d: bad feature counts", k);
+        if (k > 0 && b.in_features != blocks[k - 1].out_features)
+            return fail(CSMPN_ERR_INVALID, "block %d: in_features %d != previous out_features %d", k, b.in_features,
+                        blocks[k - 1].out_features);
+        if (!b.lin_w || !b.silu_a || !b.silu_b || !b.gp_w || !b.norm_a || !b.right_w || !b.left_w || !b.left_b || !b.ln_a)
+            return fail(CSMPN_ERR_INVALID, "block %d: null parameter pointer", k);
+        maxO = b.out_features > maxO ? b.out_features : maxO;
+        maxCPo = rup(b.out_features, 4) > maxCPo ? rup(b.out_features, 4) : maxCPo;
+    }
+    const int MT = cdiv(maxO, 16);
+    if (MT > 8) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 128 not supported", maxO);
+    C.MT = MT;
+    plan.multi = MT > 1;
+
+    const size_t need = packed_f4_count(G, blocks, nblk) * sizeof(f4);
+    if (workspace_bytes < need || !workspace) return fail(CSMPN_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need);
+    f4* ws = reinterpret_cast<f4*>(workspace);
+    PackDesc& PD = plan.P;
+    PD.G = G;
+    size_t cursor = 0;
+    int mirror = 0;
+    auto add_seg = [&](const float* w, int O, int I, int has_grades, int transposed, int NT, int KK) -> const f4* {
+        PackSeg& s = PD.seg[PD.nseg++];
+        s.w = w; s.dst = ws + cursor; s.O = O; s.I = I; s.has_grades = has_grades; s.transposed = transposed;
+        s.NT = NT; s.KK = KK; s.count = G * NT * KK * 64;
+        PD.total += s.count;
+        const f4* p = s.dst;
+        cursor += (size_t)s.count;
+        return p;
+    };
+    for (int k = 0; k < nblk; ++k) {
+        const csmpn_block_params& b = blocks[k];
+        DevBlock& B = C.b[k];
+        B.I = b.in_features; B.O = b.out_features;
+        B.KKi = cdiv(B.I, 16); B.KKo = cdiv(B.O, 16);
+        B.CPi = rup(B.I, 4); B.CPo = rup(B.O, 4);
+        B.has_b1 = b.lin_b != nullptr;
+        B.w1_sub = b.lin_subspaces ? 1 : 0;
+        B.b1 = b.lin_b; B.sa = b.silu_a; B.sb = b.silu_b; B.w = b.gp_w; B.an = b.norm_a; B.bL = b.left_b; B.la = b.ln_a;
+        B.pfW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 0, B.KKo, B.KKi);
+        B.pfWR = add_seg(b.right_w, B.O, B.O, 1, 0, B.KKo, B.KKo);
+        B.pfWL = add_seg(b.left_w, B.O, B.O, 1, 0, B.KKo, B.KKo);
+        B.pbW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 1, B.KKi, B.KKo);
+        B.pbWR = add_seg(b.right_w, B.O, B.O, 1, 1, B.KKo, B.KKo);
+        B.pbWL = add_seg(b.left_w, B.O, B.O, 1, 1, B.KKo, B.KKo);
+        B.lds_goff = mirror;
+        mirror += rup(mirror_floats_of(B.I, B.O, G, P, B.w1_sub), 4);
+        if (bwd) {
+            if (!grads) return fail(CSMPN_ERR_INVALID, "grads is null");
+            const csmpn_block_grads& g = grads[k];
+            if (!g.lin_w || !g.silu_a || !g.silu_b || !g.gp_w || !g.norm_a || !g.right_w || !g.left_w || !g.left_b ||
+                !g.ln_a || (B.has_b1 && !g.lin_b))
+                return fail(CSMPN_ERR_INVALID, "block %d: null gradient pointer", k);
+            B.gW1 = g.lin_w; B.gb1 = g.lin_b; B.gsa = g.silu_a; B.gsb = g.silu_b; B.gw = g.gp_w; B.gan = g.norm_a;
+            B.gWR = g.right_w; B.gWL = g.left_w; B.gbL = g.left_b; B.gla = g.ln_a;
+        }
+    }
+    plan.pack_f4 = cursor;
+
+    // LDS layout of one row tile (floats)
+    const int sz_in = 16 * (D * C.b[0].CPi + 4);
+    const int sz_o = 16 * (D * maxCPo + 4);
+    int off = 0;
+    C.off_in = off; off += sz_in;
+    C.off_p0 = off; off += (nblk >= 2) ? sz_o : 0;
+    C.off_p1 = off; off += (nblk >= 3) ? sz_o : 0;
+    C.off_z = off; off += sz_o;
+    C.off_g = off;
+    int sz_g = bwd ? sz_o : 0;
+    if (stage_rowlen > 0 && 16 * stage_rowlen > sz_g) sz_g = rup(16 * stage_rowlen, 4);
+    off += sz_g;
+    C.off_red = off; off += plan.multi ? rup(MT * 16, 4) : 0;
+    C.tile_floats = off;
+    const size_t tile_bytes = (size_t)off * 4;
+
+    // choose row tiles per workgroup / workgroups per CU
+    const int max_rt = 8 / MT;
+    int best_rt = 0, best_wgs = 1, best_mirror = 0;
+    for (int use_mirror = (bwd ? 1 : 0); use_mirror >= 0 && best_rt == 0; --use_mirror) {
+        const size_t mbytes = use_mirror ? (size_t)mirror * 4 : 0;
+        int best_waves = 0;
+        for (int wgs = 1; wgs <= 2; ++wgs) {
+            const size_t budget = (size_t)kMaxLdsBytes / wgs;
+            if (budget <= mbytes) continue;
+            int rt = (int)((budget - mbytes) / tile_bytes);
+            if (rt > max_rt) rt = max_rt;
+            if (rt < 1) continue;
+            const int waves = wgs * rt * MT;
+            if (waves > best_waves) { best_waves = waves; best_rt = rt; best_wgs = wgs; best_mirror = use_mirror; }
+        }
+    }
+    if (best_rt == 0) return fail(CSMPN_ERR_UNSUPPORTED, "row tile needs %zu bytes of LDS: configuration too large", tile_bytes);
+    C.RT = best_rt;
+    C.grads_in_lds = best_mirror;
+    C.mirror_floats = best_mirror ? mirror : 0;
+    plan.threads = (unsigned)(best_rt * MT * 64);
+    plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)best_rt * tile_bytes;
+    plan.grid_cap = 256u * (unsigned)best_wgs;
+    return CSMPN_OK;
+}
+
+int run_pack(const Plan& plan, hipStream_t st) {
+    if (plan.P.total == 0) return CSMPN_OK;
+    const unsigned block = 256, grid = (unsigned)((plan.P.total + block - 1) / block);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(block), 0, st, plan.P);
+    HIP_TRY(hipGetLastError());
+    return CSMPN_OK;
+}
+
+int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, hipStream_t st) {
+    if (io.rows <= 0) return CSMPN_OK;
+    const long ntiles = (io.rows + 15) / 16;
+    long grid = (ntiles + plan.C.RT - 1) / plan.C.RT;
+    if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
+    HIP_TRY(launch_cemlp(id, mode, plan.multi, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
+    return CSMPN_OK;
+}
+
+// ----------------------------------------------------------------------------- CSR build kernels
+__global__ void csr_count_kernel(const int64_t* dst, long E, int* deg) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E) atomicAdd(deg + dst[e], 1);
+}
+
+// exclusive scan of deg[0..N) into row_ptr[0..N], single workgroup of 1024 threads
+__global__ void csr_scan_kernel(const int* deg, int* row_ptr, int* cursor, long N) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (long base = 0; base < N; base += 1024) {
+        const long i = base + threadIdx.x;
+        const int v = i < N ? deg[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            int t = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const int incl = part[threadIdx.x];
+        if (i < N) { row_ptr[i] = carry + incl - v; cursor[i] = carry + incl - v; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_ptr[N] = carry;
+}
+
+__global__ void csr_fill_kernel(const int64_t* ei, long E, int* cursor, int* perm, int* src_s, int* dst_s) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int d = (int)ei[E + e], s = (int)ei[e];
+    const int pos = atomicAdd(cursor + d, 1);
+    perm[pos] = (int)e; src_s[pos] = s; dst_s[pos] = d;
+}
+
+// make the order inside each target segment canonical (ascending original edge id):
+// one thread per node, insertion sort of its (short) segment
+__global__ void csr_canon_kernel(const int* row_ptr, long N, int* perm, int* src_s) {
+    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= N) return;
+    const int b = row_ptr[v], e = row_ptr[v + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int kp = perm[i], ks = src_s[i];
+        int j = i - 1;
+        while (j >= b && perm[j] > kp) { perm[j + 1] = perm[j]; src_s[j + 1] = src_s[j]; --j; }
+        perm[j + 1] = kp; src_s[j + 1] = ks;
+    }
+}
+
+}  // namespace
+
+// =============================================================================== C-ABI
+extern "C" {
+
+const char* csmpn_last_error(void) { return g_err; }
+int csmpn_abi_version(void) { return 1; }
+const char* csmpn_build_target(void) { return "gfx950"; }
+
+int csmpn_metric_supported(const float* metric_host, int n) { return alg_id(metric_host, n) != ALG_NONE ? 1 : 0; }
+
+int csmpn_algebra_tables(const float* metric, int n, float* cayley, int64_t* index_to_bitmap, int64_t* bitmap_to_index,
+                         int64_t* grades, int64_t* subspaces, uint8_t* paths) {
+    if (!metric || n < 1 || n > 8) return fail(CSMPN_ERR_INVALID, "n=%d not in 1..8", n);
+    const int D = 1 << n, G = n + 1;
+    std::vector<int> bm(D), idx(D), gr(D);
+    int pos = 0;
+    for (int g = 0; g <= n; ++g) {
+        // combinations of g generators in lexicographic order (metric.py:18-29)
+        std::vector<int> comb(g);
+        for (int t = 0; t < g; ++t) comb[t] = t;
+        while (true) {
+            int b = 0;
+            for (int t = 0; t < g; ++t) b |= 1 << comb[t];
+            bm[pos] = b; gr[pos] = g; idx[b] = pos; ++pos;
+            int t = g - 1;
+            while (t >= 0 && comb[t] == n - g + t) --t;
+            if (t < 0) break;
+            ++comb[t];
+            for (int u = t + 1; u < g; ++u) comb[u] = comb[u - 1] + 1;
+        }
+    }
+    if (index_to_bitmap) for (int i = 0; i < D; ++i) index_to_bitmap[i] = bm[i];
+    if (bitmap_to_index) for (int i = 0; i < D; ++i) bitmap_to_index[i] = idx[i];
+    if (grades) for (int i = 0; i < D; ++i) grades[i] = gr[i];
+    if (subspaces) {
+        for (int g = 0; g < G; ++g) subspaces[g] = 0;
+        for (int i = 0; i < D; ++i) subspaces[gr[i]] += 1;
+    }
+    if (cayley) memset(cayley, 0, sizeof(float) * (size_t)D * D * D);
+    if (paths) memset(paths, 0, (size_t)G * G * G);
+    for (int i = 0; i < D; ++i)
+        for (int k = 0; k < D; ++k) {
+            const unsigned a = (unsigned)bm[i], b = (unsigned)bm[k];
+            // metric.py:50-79: reordering sign times the metric of the shared generators
+            int s = 0;
+            for (unsigned t = a >> 1; t; t >>= 1) s += popcount_u(t & b);
+            float coeff = (s & 1) ? -1.0f : 1.0f;
+            for (int bit = 0; bit < n; ++bit)
+                if ((a & b) >> bit & 1u) coeff *= metric[bit];
+            const int j = idx[a ^ b];
+            if (cayley) cayley[((size_t)i * D + j) * D + k] = coeff;
+            if (paths && coeff != 0.0f) paths[(gr[i] * G + gr[j]) * G + gr[k]] = 1;
+        }
+    return CSMPN_OK;
+}
+
+int csmpn_geometric_product_forward(const float* metric, int n, const float* a, const float* b, float* out,
+                                    int64_t rows, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    HIP_TRY(launch_gp(id, false, a, b, nullptr, out, nullptr, nullptr, rows, (hipStream_t)stream));
+    return CSMPN_OK;
+}
+
+int csmpn_geometric_product_backward(const float* metric, int n, const float* a, const float* b, const float* gout,
+                                     float* ga, float* gb, int64_t rows, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    HIP_TRY(launch_gp(id, true, a, b, gout, nullptr, ga, gb, rows, (hipStream_t)stream));
+    return CSMPN_OK;
+}
+
+size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks) {
+    if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
+    return packed_f4_count(n + 1, blocks, n_blocks) * sizeof(f4);
+}
+
+int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,
+                        int64_t rows, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    Plan plan;
+    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan);
+    if (rc) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    RowIO io;
+    memset(&io, 0, sizeof(io));
+    io.rows = rows; io.nseg = 1;
+    io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
+    io.y = y;
+    return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream);
+}
+
+int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
+                         int n_blocks, const float* x, const float* gy, int64_t rows, float* gx, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    Plan plan;
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
+    if (rc) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    RowIO io;
+    memset(&io, 0, sizeof(io));
+    io.rows = rows; io.nseg = 1;
+    io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
+    io.gy = gy; io.gx[0] = gx;
+    return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream);
+}
+
+int csmpn_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* perm, int32_t* src_sorted,
+                    int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr, int32_t* scratch, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 0 || E < 0 || N >= (1ll << 31) || E >= (1ll << 31)) return fail(CSMPN_ERR_INVALID, "bad sizes N=%lld E=%lld", (long long)N, (long long)E);
+    HIP_TRY(hipMemsetAsync(in_degree, 0, sizeof(int) * (size_t)N, st));
+    if (E > 0) {
+        const unsigned block = 256, grid = (unsigned)((E + block - 1) / block);
+        hipLaunchKernelGGL(csr_count_kernel, dim3(grid), dim3(block), 0, st, edge_index + E, (long)E, in_degree);
+    }
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, in_degree, row_ptr, scratch, (long)N);
+    if (E > 0) {
+        const unsigned block = 256, grid = (unsigned)((E + block - 1) / block);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(grid), dim3(block), 0, st, edge_index, (long)E, scratch, perm, src_sorted, dst_sorted);
+        const unsigned gridn = (unsigned)((N + block - 1) / block);
+        hipLaunchKernelGGL(csr_canon_kernel, dim3(gridn), dim3(block), 0, st, row_ptr, (long)N, perm, src_sorted);
+    }
+    HIP_TRY(hipGetLastError());
+    return CSMPN_OK;
+}
+
+int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
+                            int32_t channels, const float* edge_attr, int32_t attr_channels, const int32_t* perm,
+                            const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N, float* agg,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
+    if (channels + attr_channels != blocks[0].in_features)
+        return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
+    const int D = 1 << n;
+    Plan plan;
+    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false,
+                       blocks[n_blocks - 1].out_features * D, plan);
+    if (rc) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    RowIO io;
+    memset(&io, 0, sizeof(io));
+    io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
+    io.seg[0].a = h; io.seg[0].ia = dst_sorted; io.seg[0].b = h; io.seg[0].ib = src_sorted; io.seg[0].ch = channels;
+    io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
+    io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
+    (void)N;
+    return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream);
+}
+
+int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_params* blocks,
+                             const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
+                             const float* edge_attr, int32_t attr_channels, const int32_t* perm,
+                             const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N,
+                             const float* g_agg, float* gh, float* g_edge_attr, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
+    if (channels + attr_channels != blocks[0].in_features)
+        return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
+    Plan plan;
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
+    if (rc) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    RowIO io;
+    memset(&io, 0, sizeof(io));
+    io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
+    io.seg[0].a = h; io.seg[0].ia = dst_sorted; io.seg[0].b = h; io.seg[0].ib = src_sorted; io.seg[0].ch = channels;
+    io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
+    io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
+    io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr;
+    (void)N;
+    return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream);
+}
+
+static int node_io(const csmpn_block_params* blocks, int n_blocks, const float* h, int channels, const float* agg,
+                   int agg_channels, const float* node_attr, int attr_channels, const int32_t* in_degree,
+                   int mean_aggr, int residual, int64_t N, RowIO& io) {
+    if (attr_channels > 0 && !node_attr) return fail(CSMPN_ERR_INVALID, "node_attr is null");
+    if (channels + agg_channels + attr_channels != blocks[0].in_features)
+        return fail(CSMPN_ERR_INVALID, "node model in_features %d != %d + %d + %d", blocks[0].in_features, channels,
+                    agg_channels, attr_channels);
+    if (residual && blocks[n_blocks - 1].out_features != channels)
+        return fail(CSMPN_ERR_INVALID, "residual needs out_features == channels");
+    if (mean_aggr && !in_degree) return fail(CSMPN_ERR_INVALID, "in_degree is null");
+    memset(&io, 0, sizeof(io));
+    io.rows = N; io.nseg = attr_channels > 0 ? 3 : 2;
+    io.seg[0].a = h; io.seg[0].ch = channels; io.seg[0].off = 0;
+    io.seg[1].a = agg; io.seg[1].ch = agg_channels; io.seg[1].off = channels;
+    io.seg[1].deg = mean_aggr ? in_degree : nullptr;
+    io.seg[2].a = node_attr; io.seg[2].ch = attr_channels; io.seg[2].off = channels + agg_channels;
+    return CSMPN_OK;
+}
+
+int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
+                            int32_t channels, const float* agg, int32_t agg_channels, const float* node_attr,
+                            int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr, int32_t residual,
+                            int64_t N, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    RowIO io;
+    int rc = node_io(blocks, n_blocks, h, channels, agg, agg_channels, node_attr, attr_channels, in_degree, mean_aggr,
+                     residual, N, io);
+    if (rc) return rc;
+    Plan plan;
+    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan))) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    io.y = out; io.resid = residual ? h : nullptr;
+    return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream);
+}
+
+int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_params* blocks,
+                             const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
+                             const float* agg, int32_t agg_channels, const float* node_attr, int32_t attr_channels,
+                             const int32_t* in_degree, int32_t mean_aggr, int32_t residual, int64_t N,
+                             const float* g_out, float* gh, float* g_agg, float* g_node_attr, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    RowIO io;
+    int rc = node_io(blocks, n_blocks, h, channels, agg, agg_channels, node_attr, attr_channels, in_degree, mean_aggr,
+                     residual, N, io);
+    if (rc) return rc;
+    Plan plan;
+    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan))) return rc;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
+    io.resid_bwd = residual ? 1 : 0;
+    return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+/* csmpn_hip.h — C-ABI of the MI355X (gfx950) implementation of the Clifford
+ * geometric-product / CEMLP / shared simplicial message-passing hot path.
+ *
+ * The reference exposes this path as a PyTorch nn.Module surface, not an FFI;
+ * each entry point below cites the reference interface it replaces
+ * (paths relative to the reference repository root):
+ *
+ *   csmpn_algebra_tables      CliffordAlgebra.__init__ / construct_gmt /
+ *                             geometric_product_paths
+ *                             (csmpn/algebra/cliffordalgebra.py:11-42,238-252,
+ *                              csmpn/algebra/metric.py:18-120)
+ *   csmpn_geometric_product_* CliffordAlgebra.geometric_product
+ *                             (csmpn/algebra/cliffordalgebra.py:44-54), full-blade form
+ *   csmpn_cemlp_*             CEMLP.forward and autograd through it: MVLinear,
+ *                             MVSiLU, SteerableGeometricProductLayer (+ Normalization-
+ *                             Layer), MVLayerNorm (csmpn/models/cegnn_utils.py:34-213,287-338)
+ *   csmpn_egcl_*              EGCL.forward = PyG propagate: gather h_i/h_j, message
+ *                             (edge CEMLP), scatter sum|mean over edge_index[1],
+ *                             update (node CEMLP + residual)
+ *                             (csmpn/models/cegnn_utils.py:216-284)
+ *   csmpn_csr_build           the sort PyG/torch_scatter do not need but the
+ *                             segmented scatter here does; one-time per complex
+ *
+ * Conventions: extern "C", plain pointers and sizes, int status return
+ * (0 = ok, non-zero = error, message via csmpn_last_error()). All data
+ * pointers are DEVICE pointers to contiguous fp32 (indices int32) unless a
+ * parameter says "host". Every launch is asynchronous on the caller-supplied
+ * hipStream_t (passed as void*). No entry point allocates device memory: the
+ * caller provides the workspace (csmpn_*_workspace_bytes). Parameter tensors
+ * are read in the reference's own state_dict layouts;
+ * gradient tensors are ACCUMULATED (+=) in the same layouts and must be
+ * zero-initialised by the caller when a fresh gradient is wanted.
+ */
+#ifndef CSMPN_HIP_H
+#define CSMPN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSMPN_MAX_BLOCKS 4
+#define CSMPN_OK 0
+#define CSMPN_ERR_UNSUPPORTED 1
+#define CSMPN_ERR_INVALID 2
+#define CSMPN_ERR_HIP 3
+
+/* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
+ * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
+typedef struct csmpn_block_params {
+    int32_t in_features;
+    int32_t out_features;
+    int32_t lin_subspaces;   /* 1: lin_w is [O,I,G]; 0: [O,I] (MVLinear subspaces=False) */
+    int32_t reserved;
+    const float* lin_w;      /* layers.k.0.weight */
+    const float* lin_b;      /* layers.k.0.bias [1,O,1] or NULL */
+    const float* silu_a;     /* layers.k.1.a [1,O,G] */
+    const float* silu_b;     /* layers.k.1.b [1,O,G] */
+    const float* gp_w;       /* layers.k.2.weight [O,P] */
+    const float* norm_a;     /* layers.k.2.normalization.a [O,G] */
+    const float* right_w;    /* layers.k.2.linear_right.weight [O,O,G] */
+    const float* left_w;     /* layers.k.2.linear_left.weight [O,O,G] */
+    const float* left_b;     /* layers.k.2.linear_left.bias [1,O,1] */
+    const float* ln_a;       /* layers.k.3.a [1,O] */
+} csmpn_block_params;
+
+/* Gradient accumulators, same shapes as csmpn_block_params' tensors. */
+typedef struct csmpn_block_grads {
+    float* lin_w;
+    float* lin_b;            /* NULL iff lin_b is NULL */
+    float* silu_a;
+    float* silu_b;
+    float* gp_w;
+    float* norm_a;
+    float* right_w;
+    float* left_w;
+    float* left_b;
+    float* ln_a;
+} csmpn_block_grads;
+
+/* Algebra: metric is a HOST array of n floats, every entry +1 or -1,
+ * 2 <= n <= 5 for the device entry points (csmpn_metric_supported). */
+int csmpn_metric_supported(const float* metric_host, int n);
+
+/* Host-side table construction (any diagonal metric, n <= 8). All outputs are
+ * HOST arrays: cayley [D*D*D] (left,out,right), index_to_bitmap [D],
+ * bitmap_to_index [D], grades [D] (int64), subspaces [n+1] (int64),
+ * paths [(n+1)^3] (uint8, (grade_left, grade_out, grade_right)). Any output
+ * pointer may be NULL. */
+int csmpn_algebra_tables(const float* metric_host, int n, float* cayley, int64_t* index_to_bitmap,
+                         int64_t* bitmap_to_index, int64_t* grades, int64_t* subspaces, uint8_t* paths);
+
+/* out[r, :] = a[r, :] * b[r, :] (geometric product), rows x D. Backward:
+ * ga += d/da, gb += d/db given gout. */
+int csmpn_geometric_product_forward(const float* metric_host, int n, const float* a, const float* b,
+                                    float* out, int64_t rows, void* stream);
+int csmpn_geometric_product_backward(const float* metric_host, int n, const float* a, const float* b,
+                                     const float* gout, float* ga, float* gb, int64_t rows, void* stream);
+
+/* Workspace (bytes) for a CEMLP of these blocks; covers packed weights and
+ * per-launch scratch for any entry point below that takes this CEMLP. */
+size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks);
+
+/* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
+int csmpn_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
+                        const float* x, int64_t rows, float* y, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+/* gx[rows, I_0, D] = d<gy,y>/dx (overwritten; may be NULL), grads += d/dparams.
+ * Recomputes the forward in-kernel from x. */
+int csmpn_cemlp_backward(const float* metric_host, int n, const csmpn_block_params* blocks,
+                         const csmpn_block_grads* grads, int n_blocks, const float* x, const float* gy,
+                         int64_t rows, float* gx, void* workspace, size_t workspace_bytes, void* stream);
+
+/* One-time per complex: sort the E directed adjacencies by target.
+ * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
+ * Outputs (device): perm[E] (sorted position -> original edge id), src_sorted[E],
+ * dst_sorted[E] (int32), in_degree[N] (int32), row_ptr[N+1] (int32).
+ * scratch: N+1 int32. The order inside one target's segment is unspecified. */
+int csmpn_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
+                    int32_t* src_sorted, int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr,
+                    int32_t* scratch, void* stream);
+
+/* EGCL message + aggregate (cegnn_utils.py:254-262 + PyG scatter):
+ *   agg[v] += sum_{e: dst_e = v} EdgeCEMLP(cat_c[h[dst_e] - h[src_e], edge_attr[perm_e]])
+ * agg [N, O, D] must be zeroed by the caller. edge_attr [E, A, D] in ORIGINAL edge
+ * order (or NULL when A = 0). The mean's 1/max(deg,1) is applied by the node
+ * entry points. */
+int csmpn_egcl_edge_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
+                            const float* h, int32_t channels, const float* edge_attr, int32_t attr_channels,
+                            const int32_t* perm, const int32_t* src_sorted, const int32_t* dst_sorted,
+                            int64_t n_edges, int64_t n_nodes, float* agg, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* Backward of the above. g_agg [N,O,D] is d/d(agg) (already divided by the degree
+ * for aggr=mean). gh [N,C,D] += (scatter of +g to dst, -g to src);
+ * g_edge_attr [E,A,D] (original order, overwritten) may be NULL. */
+int csmpn_egcl_edge_backward(const float* metric_host, int n, const csmpn_block_params* blocks,
+                             const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
+                             const float* edge_attr, int32_t attr_channels, const int32_t* perm,
+                             const int32_t* src_sorted, const int32_t* dst_sorted, int64_t n_edges,
+                             int64_t n_nodes, const float* g_agg, float* gh, float* g_edge_attr,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* EGCL update (cegnn_utils.py:264-275):
+ *   out[v] = (residual ? h[v] : 0) + NodeCEMLP(cat_c[h[v], agg[v] * s_v, node_attr[v]])
+ * s_v = 1/max(in_degree[v],1) if mean_aggr else 1. node_attr [N,T,D] or NULL. */
+int csmpn_egcl_node_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
+                            const float* h, int32_t channels, const float* agg, int32_t agg_channels,
+                            const float* node_attr, int32_t attr_channels, const int32_t* in_degree,
+                            int32_t mean_aggr, int32_t residual, int64_t n_nodes, float* out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of the above: gh [N,C,D] (overwritten) = d/dh incl. residual,
+ * g_agg [N,O,D] (overwritten) = d/d(agg) incl. the mean scale,
+ * g_node_attr [N,T,D] (overwritten) may be NULL. */
+int csmpn_egcl_node_backward(const float* metric_host, int n, const csmpn_block_params* blocks,
+                             const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
+                             const float* agg, int32_t agg_channels, const float* node_attr,
+                             int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr,
+                             int32_t residual, int64_t n_nodes, const float* g_out, float* gh, float* g_agg,
+                             float* g_node_attr, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Last error message of the calling thread (never NULL). */
+const char* csmpn_last_error(void);
+
+/* Library/ABI version and the gfx target it was built for. */
+int csmpn_abi_version(void);
+const char* csmpn_build_target(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSMPN_HIP_H */

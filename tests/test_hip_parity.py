@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against (a) the golden vectors
+captured from the imported reference and (b) the oracle on seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-5 relative, fp32 — measured as
+max|hip - ref| / max|ref| per tensor against the float64 reference values, with the
+reference's own float32 CPU run as the yardstick: the HIP result must be within
+max(1e-5, 4 x the error of the reference's fp32 run) of the fp64 truth.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_path as O
+
+pytestmark = pytest.mark.gpu
+
+ALGS = ["cl20", "cl30", "cl50", "cl41"]
+TOL = 1e-5
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def check(name, hip, truth, ref32=None, tol=TOL, slack=4.0):
+    err = relmax(hip, truth)
+    bound = tol
+    if ref32 is not None:
+        bound = max(tol, slack * relmax(ref32, truth))
+    assert err <= bound, f"{name}: rel err {err:.3e} > {bound:.3e}"
+    return err
+
+
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def load(golden_dir, kind, name):
+    return np.load(os.path.join(golden_dir, f"{kind}_{name}.npz"))
+
+
+@pytest.mark.parametrize("name", ALGS)
+def test_geometric_product(pkg, golden_dir, name):
+    g = load(golden_dir, "algebra", name)
+    t = load(golden_dir, "tables", name)
+    alg = pkg.CliffordAlgebra(tuple(t["metric"].tolist())).to(dev())
+    a = torch.from_numpy(g["a"]).to(dev()).requires_grad_(True)
+    b = torch.from_numpy(g["b"]).to(dev()).requires_grad_(True)
+    out = alg.geometric_product(a, b)
+    check("gp", out.detach().cpu().numpy(), g["gp"])
+    # backward vs the dense einsum autograd on CPU
+    oa = O.Algebra(t["metric"].tolist(), torch.float64)
+    a64 = torch.from_numpy(g["a"]).double().requires_grad_(True)
+    b64 = torch.from_numpy(g["b"]).double().requires_grad_(True)
+    w = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).double()
+    (O.geometric_product(oa, a64, b64) * w).sum().backward()
+    (out * w.float().to(dev())).sum().backward()
+    check("gp.ga", a.grad.cpu().numpy(), a64.grad.numpy())
+    check("gp.gb", b.grad.cpu().numpy(), b64.grad.numpy())
+
+
+def _set_block_params(seq, p, prefix):
+    m = {"0.weight": seq[0].weight, "0.bias": seq[0].bias, "1.a": seq[1].a, "1.b": seq[1].b, "2.weight": seq[2].weight,
+         "2.normalization.a": seq[2].normalization.a, "2.linear_right.weight": seq[2].linear_right.weight,
+         "2.linear_left.weight": seq[2].linear_left.weight, "2.linear_left.bias": seq[2].linear_left.bias,
+         "3.a": seq[3].a}
+    with torch.no_grad():
+        for k, prm in m.items():
+            prm.copy_(torch.as_tensor(p[prefix + k]))
+    return m
+
+
+@pytest.mark.parametrize("name", ALGS)
+@pytest.mark.parametrize("C", [3, 8])
+@pytest.mark.parametrize("nl", [1, 2])
+def test_cemlp_golden(pkg, golden_dir, name, C, nl):
+    g = load(golden_dir, "layers", name)
+    t = load(golden_dir, "tables", name)
+    tag = f"cemlp{nl}_C{C}"
+    alg = pkg.CliffordAlgebra(tuple(t["metric"].tolist()))
+    m = pkg.CEMLP(alg, C, 5, 4, n_layers=nl).to(dev())
+    maps = []
+    for k, seq in enumerate(m.layers):
+        maps.append(_set_block_params(seq, {kk[len(tag) + 3:]: g[kk] for kk in g.files if kk.startswith(tag + "/p/")},
+                                      f"layers.{k}."))
+    x = torch.from_numpy(g[f"{tag}/x"]).to(dev()).requires_grad_(True)
+    y = m(x)
+    # truth: oracle in float64 on the same inputs (pinned to the reference by test_oracle_golden)
+    oa = O.Algebra(t["metric"].tolist(), torch.float64)
+    p64 = {kk[len(tag) + 3:]: torch.from_numpy(g[kk]).double().requires_grad_(True) for kk in g.files if kk.startswith(tag + "/p/")}
+    x64 = torch.from_numpy(g[f"{tag}/x"]).double().requires_grad_(True)
+    y64 = O.cemlp(oa, x64, p64)
+    gout = torch.from_numpy(g[f"{tag}/gout"])
+    (y64 * gout.double()).sum().backward()
+    (y * gout.to(dev())).sum().backward()
+    check(tag + ".y", y.detach().cpu().numpy(), y64.detach().numpy(), g[f"{tag}/y"])
+    check(tag + ".gx", x.grad.cpu().numpy(), x64.grad.numpy(), g[f"{tag}/gx"])
+    for k, mp in enumerate(maps):
+        for key, prm in mp.items():
+            full = f"layers.{k}.{key}"
+            check(f"{tag}.g.{full}", prm.grad.cpu().numpy(), p64[full].grad.numpy(), g[f"{tag}/g/{full}"])
+
+
+EGCL_TAGS = ["sum_res1_ag0", "sum_res1_ag1", "sum_res0_ag0", "mean_res1_ag0", "mean_res1_ag1", "mean_res0_ag0", "noattr"]
+
+
+@pytest.mark.parametrize("name", ALGS)
+@pytest.mark.parametrize("variant", EGCL_TAGS)
+def test_egcl_golden(pkg, golden_dir, name, variant):
+    g = load(golden_dir, "egcl", name)
+    t = load(golden_dir, "tables", name)
+    f32, f64 = f"f32/{variant}", f"f64/{variant}"
+    alg = pkg.CliffordAlgebra(tuple(t["metric"].tolist()))
+    N, C, D = g[f"{f32}/h"].shape
+    noattr = variant == "noattr"
+    aggr = "mean" if noattr else variant.split("_")[0]
+    residual = "res0" not in variant
+    ag = variant.endswith("ag1")
+    layer = pkg.EGCL(alg, C, C + 1 if noattr else C, C, edge_attr_features=0 if noattr else 6,
+                     node_attr_features=0 if noattr else 3, residual=residual, aggr=aggr).to(dev())
+    sd = layer.state_dict()
+    for k in list(sd):
+        if f"{f32}/p/{k}" in g.files:
+            sd[k] = torch.from_numpy(g[f"{f32}/p/{k}"])
+    layer.load_state_dict(sd, strict=True)
+    h = torch.from_numpy(g[f"{f32}/h"]).to(dev()).requires_grad_(True)
+    ei = torch.from_numpy(g[f"{f32}/edge_index"]).to(dev())
+    ea = na = None
+    if not noattr:
+        ea = torch.from_numpy(g[f"{f32}/edge_attr"]).to(dev()).requires_grad_(ag)
+        na = torch.from_numpy(g[f"{f32}/node_attr"]).to(dev()).requires_grad_(ag)
+    y = layer(h, ei, ea, na)
+    (y * torch.from_numpy(g[f"{f32}/gout"]).to(dev())).sum().backward()
+    check("y", y.detach().cpu().numpy(), g[f"{f64}/y"], g[f"{f32}/y"])
+    check("gh", h.grad.cpu().numpy(), g[f"{f64}/gh"], g[f"{f32}/gh"])
+    if ag:
+        check("g_edge_attr", ea.grad.cpu().numpy(), g[f"{f64}/g_edge_attr"], g[f"{f32}/g_edge_attr"])
+        check("g_node_attr", na.grad.cpu().numpy(), g[f"{f64}/g_node_attr"], g[f"{f32}/g_node_attr"])
+    for k, prm in layer.named_parameters():
+        check("g." + k, prm.grad.cpu().numpy(), g[f"{f64}/g/{k}"], g[f"{f32}/g/{k}"])
+
+
+def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True):
+    """Seeded synthetic complex; HIP layer vs the float64 oracle with identical parameters."""
+    import importlib
+    pkg = importlib.import_module("clifford-group-equivariant-simplicial-message-passing-networks_amd")
+    oa = O.Algebra(metric, torch.float64)
+    o32 = O.Algebra(metric, torch.float32)
+    h, ei, ea, na = O.synthetic_complex(o32, N, E, C, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    p = O.init_egcl_params(o32, C, hidden, C, 6, 3, gen=gen, randomize=True)
+    alg = pkg.CliffordAlgebra(tuple(metric))
+    layer = pkg.EGCL(alg, C, hidden, C, edge_attr_features=6, node_attr_features=3, residual=residual, aggr=aggr)
+    sd = layer.state_dict()
+    for k, v in p.items():
+        sd[k] = v
+    layer.load_state_dict(sd, strict=True)
+    layer = layer.to(dev())
+    hd = h.to(dev()).requires_grad_(True)
+    y = layer(hd, ei.to(dev()), ea.to(dev()), na.to(dev()))
+    gout = torch.randn(y.shape, generator=gen)
+    (y * gout.to(dev())).sum().backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    h64 = h.double().requires_grad_(True)
+    y64 = O.egcl(oa, h64, ei, ea.double(), na.double(), p64, aggr=aggr, residual=residual)
+    (y64 * gout.double()).sum().backward()
+    # float32 oracle run as the yardstick
+    p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    h32 = h.clone().requires_grad_(True)
+    y32 = O.egcl(o32, h32, ei, ea, na, p32, aggr=aggr, residual=residual)
+    (y32 * gout).sum().backward()
+    errs = {"y": check("y", y.detach().cpu().numpy(), y64.detach().numpy(), y32.detach().numpy()),
+            "gh": check("gh", hd.grad.cpu().numpy(), h64.grad.numpy(), h32.grad.numpy())}
+    for k, prm in layer.named_parameters():
+        errs[k] = check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy())
+    return errs
+
+
+@pytest.mark.parametrize("metric,C,hidden,aggr", [
+    ((1.0, 1.0, 1.0), 8, 8, "mean"),            # S1 shape (reduced N/E)
+    ((1.0, 1.0, 1.0), 16, 16, "mean"),          # S2 shape
+    ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 8, "mean"), # S3 shape
+    ((1.0, 1.0, 1.0), 32, 32, "sum"),           # md17 shape: two channel tiles per row tile
+    ((1.0, 1.0, 1.0, 1.0, 1.0), 28, 28, "mean"),# hulls shape: 28 channels, Cl(5,0)
+    ((1.0, 1.0), 40, 40, "sum"),                # nba shape: Cl(2,0), 40 channels
+    ((1.0, 1.0, 1.0), 7, 20, "sum"),            # ragged: hidden != in/out, odd channel counts
+])
+def test_egcl_vs_oracle_shapes(pkg, metric, C, hidden, aggr):
+    N, E = (300, 2999) if len(metric) <= 3 else (120, 1001)
+    _oracle_egcl_case(list(metric), N, E, C, hidden, aggr, seed=5)
+
+
+def test_egcl_edge_cases(pkg):
+    """Empty edge list, single node, rows not a multiple of the 16-row tile."""
+    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+    layer = pkg.EGCL(alg, 4, 4, 4, aggr="mean").to(dev())
+    h = torch.randn(3, 4, 8, device=dev(), requires_grad=True)
+    ei = torch.zeros(2, 0, dtype=torch.int64, device=dev())
+    y = layer(h, ei)
+    y.sum().backward()
+    # no messages: out = h + node_model([h, 0])
+    oa = O.Algebra([1.0, 1.0, 1.0])
+    p = {k: v.detach().cpu() for k, v in layer.named_parameters()}
+    yo = O.egcl(oa, h.detach().cpu(), ei.cpu(), None, None, p, aggr="mean")
+    check("empty.y", y.detach().cpu().numpy(), yo.numpy(), tol=2e-5)
+    assert torch.isfinite(h.grad).all()
+    # one node, one self loop
+    h1 = torch.randn(1, 4, 8, device=dev())
+    ei1 = torch.zeros(2, 1, dtype=torch.int64, device=dev())
+    y1 = layer(h1, ei1)
+    yo1 = O.egcl(oa, h1.cpu(), ei1.cpu(), None, None, p, aggr="mean")
+    check("single.y", y1.detach().cpu().numpy(), yo1.numpy(), tol=2e-5)
+
+
+def test_scatter_linearity_full_size(pkg):
+    """Size-independent property at the full S1 size (no oracle in the loop): for aggr=sum
+    the edge stage is additive over a partition of the edge list."""
+    from csmpn_hip import ops
+    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+    N, E, C = 10_000, 100_000, 8
+    torch.manual_seed(0)
+    layer = pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr="sum", residual=False).to(dev())
+    o32 = O.Algebra([1.0, 1.0, 1.0])
+    h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(o32, N, E, C, seed=0))
+    # message aggregate of the whole list vs the sum of two halves: compare through a
+    # node model that is linear in agg? it is not, so compare agg directly via the C-ABI ops
+    spec = layer.spec()
+    from csmpn_hip import native
+    def agg_of(sel):
+        csr = ops.Csr(ei[:, sel].contiguous(), N)
+        e = spec.edge
+        e.bind(layer.edge_model.flat_params())
+        agg = torch.zeros(N, C, 8, device=dev())
+        ws = e.workspace(dev())
+        eas = ea[sel].contiguous()
+        native.check(native.lib().csmpn_egcl_edge_forward(
+            e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), C, eas.data_ptr(), 6, csr.perm.data_ptr(),
+            csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(), ws.numel(),
+            torch.cuda.current_stream().cuda_stream))
+        return agg
+    idx = torch.arange(E, device=dev())
+    full = agg_of(idx)
+    parts = agg_of(idx[: E // 3]) + agg_of(idx[E // 3:])
+    torch.cuda.synchronize()
+    assert relmax(parts.cpu().numpy(), full.cpu().numpy()) < 1e-5
+    assert torch.isfinite(full).all()
+
+
+def test_csr_build(pkg):
+    from csmpn_hip import ops
+    g = torch.Generator().manual_seed(3)
+    N, E = 1000, 20_000
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :50] = 7
+    csr = ops.Csr(ei.to(dev()), N)
+    torch.cuda.synchronize()
+    perm = csr.perm.cpu().long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(E))            # a permutation
+    assert torch.equal(csr.dst.cpu().long(), ei[1][perm])
+    assert torch.equal(csr.src.cpu().long(), ei[0][perm])
+    assert torch.all(csr.dst.cpu()[1:] >= csr.dst.cpu()[:-1])               # sorted by target
+    assert torch.equal(csr.deg.cpu().long(), torch.bincount(ei[1], minlength=N))
+    rp = csr.row_ptr.cpu().long()
+    assert rp[0] == 0 and rp[-1] == E and torch.equal(rp[1:] - rp[:-1], csr.deg.cpu().long())
+    # canonical (deterministic) order inside a segment: ascending original edge id
+    seg = perm[rp[7]:rp[8]]
+    assert torch.all(seg[1:] > seg[:-1])
+
+
+def test_equivariance_rotation(pkg):
+    """O(3)-equivariance of the HIP layer: rotating every multivector input by a rotor
+    commutes with the layer (property the reference layers have)."""
+    o32 = O.Algebra([1.0, 1.0, 1.0], torch.float64)
+    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+    torch.manual_seed(1)
+    layer = pkg.EGCL(alg, 8, 8, 8, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
+    h, ei, ea, na = O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), 200, 1500, 8, seed=2)
+    # rotor = product of two unit vectors; sandwich w x w~ with w w~ = 1
+    g = torch.Generator().manual_seed(4)
+    v1 = torch.zeros(8, dtype=torch.float64); v1[1:4] = torch.randn(3, generator=g, dtype=torch.float64); v1 /= v1[1:4].norm()
+    v2 = torch.zeros(8, dtype=torch.float64); v2[1:4] = torch.randn(3, generator=g, dtype=torch.float64); v2 /= v2[1:4].norm()
+    w = O.geometric_product(o32, v1, v2)
+    wrev = torch.from_numpy(o32.t.beta).double() * w
+    def rot(x):
+        x64 = x.double()
+        return O.geometric_product(o32, O.geometric_product(o32, w.expand_as(x64), x64), wrev.expand_as(x64)).float()
+    y = layer(h.to(dev()), ei.to(dev()), ea.to(dev()), na.to(dev())).detach().cpu()
+    yr = layer(rot(h).to(dev()), ei.to(dev()), rot(ea).to(dev()), rot(na).to(dev())).detach().cpu()
+    assert relmax(yr.numpy(), rot(y).numpy()) < 2e-5
