@@ -132,6 +132,34 @@ struct Plan {
     bool multi;
 };
 
+// LDS/global floats of one 16-row tile's buffers
+struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, total; };
+TileLayout tile_layout(int D, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen) {
+    int maxO = 0, maxCPo = 0;
+    for (int k = 0; k < nblk; ++k) {
+        maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
+        maxCPo = rup(blocks[k].out_features, 4) > maxCPo ? rup(blocks[k].out_features, 4) : maxCPo;
+    }
+    const int MT = cdiv(maxO, 16);
+    const int sz_in = 16 * (D * rup(blocks[0].in_features, 4) + 4);
+    const int sz_o = 16 * (D * maxCPo + 4);
+    TileLayout L;
+    int off = 0;
+    L.off_in = off; off += sz_in;
+    L.off_p0 = off; off += (nblk >= 2) ? sz_o : 0;
+    L.off_p1 = off; off += (nblk >= 3) ? sz_o : 0;
+    L.off_z = off; off += sz_o;
+    L.off_g = off;
+    int sz_g = bwd ? sz_o : 0;
+    if (stage_rowlen > 0 && 16 * stage_rowlen > sz_g) sz_g = rup(16 * stage_rowlen, 4);
+    off += sz_g;
+    L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
+    L.total = off;
+    return L;
+}
+constexpr unsigned kGlobalTileGrid = 256;   // workgroups when the tiles live in global scratch
+inline int global_tile_rt(int MT) { int r = 4 / MT; return r < 1 ? 1 : r; }
+
 size_t packed_f4_count(int G, const csmpn_block_params* blocks, int nblk) {
     size_t tot = 0;
     for (int k = 0; k < nblk; ++k) {
@@ -217,21 +245,11 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     }
     plan.pack_f4 = cursor;
 
-    // LDS layout of one row tile (floats)
-    const int sz_in = 16 * (D * C.b[0].CPi + 4);
-    const int sz_o = 16 * (D * maxCPo + 4);
-    int off = 0;
-    C.off_in = off; off += sz_in;
-    C.off_p0 = off; off += (nblk >= 2) ? sz_o : 0;
-    C.off_p1 = off; off += (nblk >= 3) ? sz_o : 0;
-    C.off_z = off; off += sz_o;
-    C.off_g = off;
-    int sz_g = bwd ? sz_o : 0;
-    if (stage_rowlen > 0 && 16 * stage_rowlen > sz_g) sz_g = rup(16 * stage_rowlen, 4);
-    off += sz_g;
-    C.off_red = off; off += plan.multi ? rup(MT * 16, 4) : 0;
-    C.tile_floats = off;
-    const size_t tile_bytes = (size_t)off * 4;
+    // buffers of one row tile (floats)
+    const TileLayout L = tile_layout(D, blocks, nblk, bwd, stage_rowlen);
+    C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
+    C.off_red = L.off_red; C.tile_floats = L.total;
+    const size_t tile_bytes = (size_t)L.total * 4;
 
     // choose row tiles per workgroup / workgroups per CU
     const int max_rt = 8 / MT;
@@ -249,13 +267,27 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
             if (waves > best_waves) { best_waves = waves; best_rt = rt; best_wgs = wgs; best_mirror = use_mirror; }
         }
     }
-    if (best_rt == 0) return fail(CSMPN_ERR_UNSUPPORTED, "row tile needs %zu bytes of LDS: configuration too large", tile_bytes);
-    C.RT = best_rt;
-    C.grads_in_lds = best_mirror;
-    C.mirror_floats = best_mirror ? mirror : 0;
-    plan.threads = (unsigned)(best_rt * MT * 64);
-    plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)best_rt * tile_bytes;
-    plan.grid_cap = 256u * (unsigned)best_wgs;
+    if (best_rt > 0) {
+        C.RT = best_rt;
+        C.grads_in_lds = best_mirror;
+        C.mirror_floats = best_mirror ? mirror : 0;
+        C.gtiles = nullptr;
+        plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)best_rt * tile_bytes;
+        plan.grid_cap = 256u * (unsigned)best_wgs;
+    } else {
+        // tiles too large for the LDS: keep them in a global scratch behind the packed weights
+        C.RT = global_tile_rt(MT);
+        const bool mfit = bwd && (size_t)mirror * 4 <= (size_t)kMaxLdsBytes;
+        C.grads_in_lds = mfit ? 1 : 0;
+        C.mirror_floats = mfit ? mirror : 0;
+        const size_t scratch = (size_t)kGlobalTileGrid * C.RT * tile_bytes;
+        if (workspace_bytes < need + scratch)
+            return fail(CSMPN_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need + scratch);
+        C.gtiles = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + need);
+        plan.lds_bytes = (size_t)C.mirror_floats * 4;
+        plan.grid_cap = kGlobalTileGrid;
+    }
+    plan.threads = (unsigned)(C.RT * MT * 64);
     return CSMPN_OK;
 }
 
@@ -405,7 +437,14 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
 
 size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks) {
     if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
-    return packed_f4_count(n + 1, blocks, n_blocks) * sizeof(f4);
+    size_t bytes = packed_f4_count(n + 1, blocks, n_blocks) * sizeof(f4);
+    int maxO = 0;
+    for (int k = 0; k < n_blocks; ++k) maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
+    const int D = 1 << n, MT = cdiv(maxO, 16);
+    const TileLayout L = tile_layout(D, blocks, n_blocks, true, blocks[n_blocks - 1].out_features * D);
+    if ((size_t)L.total * 4 > (size_t)kMaxLdsBytes)   // tiles spill to a global scratch (see make_plan)
+        bytes += (size_t)kGlobalTileGrid * global_tile_rt(MT) * L.total * 4;
+    return bytes;
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,

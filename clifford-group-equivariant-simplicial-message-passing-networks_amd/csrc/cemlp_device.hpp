@@ -59,6 +59,7 @@ struct DevCemlp {
     int off_in, off_p0, off_p1, off_z, off_g, off_red;  // float offsets inside one row tile's LDS region
     int tile_floats;     // LDS floats per row tile
     int mirror_floats;   // LDS floats of the gradient mirror (0 if not used)
+    float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
     DevBlock b[4];
 };
 
@@ -125,18 +126,28 @@ CSMPN_DEV float quarters_sum(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
+// Accuracy: the parity bar is 1e-5 relative against the reference's fp32 CPU path, so
+// division and exp are the correctly-rounded / <=1ulp forms by default; -DCSMPN_FAST_MATH
+// switches to v_rcp_f32 / v_exp_f32 approximations (measured: up to 1.1e-5 on small grads).
+#ifdef CSMPN_FAST_MATH
 CSMPN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-CSMPN_DEV f4 rcp4(f4 x) { return f4{fast_rcp(x.x), fast_rcp(x.y), fast_rcp(x.z), fast_rcp(x.w)}; }
 CSMPN_DEV float sigmoidf(float x) { return fast_rcp(1.0f + __expf(-x)); }
+#else
+CSMPN_DEV float fast_rcp(float x) { return 1.0f / x; }
+CSMPN_DEV float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+#endif
+CSMPN_DEV f4 rcp4(f4 x) { return f4{fast_rcp(x.x), fast_rcp(x.y), fast_rcp(x.z), fast_rcp(x.w)}; }
 CSMPN_DEV f4 sigmoid4(f4 x) { return f4{sigmoidf(x.x), sigmoidf(x.y), sigmoidf(x.z), sigmoidf(x.w)}; }
 CSMPN_DEV f4 sqrt4(f4 x) { return f4{__builtin_sqrtf(x.x), __builtin_sqrtf(x.y), __builtin_sqrtf(x.z), __builtin_sqrtf(x.w)}; }
 // (q^2 + 1e-16)^(1/4)  (cliffordalgebra.py:148-149)
 CSMPN_DEV f4 smooth_abs_sqrt4(f4 q) { return sqrt4(sqrt4(q * q + kSmooth)); }
 CSMPN_DEV f4 splat(float v) { return f4{v, v, v, v}; }
 
+// GT (runtime, uniform): the tile buffers live in global memory (configurations whose
+// tiles exceed the LDS); then every exchange is a workgroup barrier + fence.
 template <bool MULTI>
-CSMPN_DEV void tile_sync() {
-    if constexpr (MULTI) {
+CSMPN_DEV void tile_sync(bool GT) {
+    if (MULTI || GT) {
         __syncthreads();
     } else {
         // one wave owns the tile: LDS operations of a wave execute in order, only
@@ -368,7 +379,7 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 // red: LDS scratch [MT][16] floats for cross-wave LayerNorm sums (MULTI only).
 template <class ALG, bool MULTI>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
-                             float* red, int MT, int mt, int lane, FwdState<ALG>& S, f4 (&out)[ALG::D]) {
+                             float* red, int MT, int mt, int lane, bool GT, FwdState<ALG>& S, f4 (&out)[ALG::D]) {
     constexpr int D = ALG::D, G = ALG::G;
     const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
     const int c = 16 * mt + (lane & 15), q = lane >> 4;
@@ -400,7 +411,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
         for (int t = 0; t < nd; ++t) z[d0 + t] = S.gate[g] * S.y[d0 + t];
     });
     store_tile<ALG>(z, zbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>();
+    tile_sync<MULTI>(GT);
 
     // 3. linear_right / linear_left (cegnn_utils.py:143-148)
     f4 L[D];
@@ -462,7 +473,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 template <class ALG, bool MULTI>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
-                              float* red, float* mirror, bool in_lds, int MT, int mt, int lane,
+                              float* red, float* mirror, bool in_lds, int MT, int mt, int lane, bool GT,
                               f4 (&gy)[ALG::D]) {
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P;
     const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
@@ -517,7 +528,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
 
     // ---- d/dz from linear_left: gz = GL . WL^T ; gWL += GL (x) Z
     store_tile<ALG>(ggp, gbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>();
+    tile_sync<MULTI>(GT);
     f4 gz[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gz[d] = splat(0.f);
@@ -559,9 +570,9 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
             gR[d] = cv ? gr[d] * S.invden[g] + gq * (2.0f * qsf<ALG, d>) * S.R[d] : splat(0.f);
         });
     });
-    tile_sync<MULTI>();   // all reads of gbuf (GL) done
+    tile_sync<MULTI>(GT);   // all reads of gbuf (GL) done
     store_tile<ALG>(gR, gbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>();
+    tile_sync<MULTI>(GT);
     if (tile_active) {
         linear_from_tile<ALG>(gz, gbuf, RSo, B.CPo, B.KKo, B.pbWR + (size_t)mt * G * B.KKo * 64, lane);
         weight_grad<ALG>(gR, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WR, in_lds, true);
@@ -593,10 +604,10 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         if (lane0q && cv) atomicAdd(d_b1 + c, t);
     }
     // ---- MVLinear weight gradient; gy tile to LDS for the transposed MVLinear
-    tile_sync<MULTI>();   // all reads of gbuf (GR) done
+    tile_sync<MULTI>(GT);   // all reads of gbuf (GR) done
     store_tile<ALG>(gy, gbuf, RSo, B.CPo, mt, lane);
     if (tile_active) weight_grad<ALG>(gy, xin, RSi, B.CPi, B.I, B.O, B.KKi, mt, lane, d_W1, in_lds, B.w1_sub != 0);
-    tile_sync<MULTI>();
+    tile_sync<MULTI>(GT);
 }
 
 // flush one block's LDS gradient mirror into the global reference-layout accumulators

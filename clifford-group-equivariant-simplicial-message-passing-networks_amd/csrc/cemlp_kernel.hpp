@@ -126,7 +126,9 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
     const int tid_rt = mt * 64 + lane, nthr_rt = MT * 64;
     const int q = lane >> 4;
     float* mirror = smem;
-    float* base = smem + C.mirror_floats + (size_t)rt * C.tile_floats;
+    const bool GT = C.gtiles != nullptr;
+    float* base = GT ? C.gtiles + ((size_t)blockIdx.x * RT + rt) * C.tile_floats
+                     : smem + C.mirror_floats + (size_t)rt * C.tile_floats;
     float* buf_in = base + C.off_in;
     float* buf_p[2] = {base + C.off_p0, base + C.off_p1};
     float* buf_z = base + C.off_z;
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
         const long tile = iter * tiles_per_iter + (long)blockIdx.x * RT + rt;
         const long row0 = tile * 16;   // may be >= rows: fully masked tile
         stage_input<ALG>(io, buf_in, RS0, B0.CPi, row0, tid_rt, nthr_rt);
-        tile_sync<MULTI>();
+        tile_sync<MULTI>(GT);
 
         if constexpr (!BWD) {
             // ------------------------------------------------------------ forward
@@ -162,22 +164,22 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                 const DevBlock& B = C.b[k];
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, 16 * mt + (lane & 15));
                 FwdState<ALG> S;
-                block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, S, out);
+                block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, GT, S, out);
                 if (k + 1 < C.nblk) {
-                    tile_sync<MULTI>();
+                    tile_sync<MULTI>(GT);
                     store_tile<ALG>(out, buf_p[k & 1], D * B.CPo + 4, B.CPo, mt, lane);
-                    tile_sync<MULTI>();
+                    tile_sync<MULTI>(GT);
                     in = buf_p[k & 1];
                 }
             }
             const int O = BL.O;
             const int c = 16 * mt + (lane & 15);
             if constexpr (MODE == MODE_EDGE) {
-                tile_sync<MULTI>();
+                tile_sync<MULTI>(GT);
                 store_dense<ALG>(out, buf_g, O, c, q);
-                tile_sync<MULTI>();
+                tile_sync<MULTI>(GT);
                 scatter_rows<ALG, !MULTI>(buf_g, O * D, io.dst, row0, io.rows, io.agg, 1.0f, tid_rt, nthr_rt);
-                tile_sync<MULTI>();
+                tile_sync<MULTI>(GT);
             } else {
                 if (c < O) {
 #pragma unroll
@@ -225,10 +227,10 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                     const LaneParams<ALG> lpj = load_lane_params<ALG>(Bj, 16 * mt + (lane & 15));
                     FwdState<ALG> Sj;
                     f4 oj[D];
-                    block_forward<ALG, MULTI>(Bj, lpj, in, buf_z, red, MT, mt, lane, Sj, oj);
-                    tile_sync<MULTI>();
+                    block_forward<ALG, MULTI>(Bj, lpj, in, buf_z, red, MT, mt, lane, GT, Sj, oj);
+                    tile_sync<MULTI>(GT);
                     store_tile<ALG>(oj, buf_p[j & 1], D * Bj.CPo + 4, Bj.CPo, mt, lane);
-                    tile_sync<MULTI>();
+                    tile_sync<MULTI>(GT);
                     in = buf_p[j & 1];
                 }
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, 16 * mt + (lane & 15));
@@ -236,8 +238,8 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                 {
                     FwdState<ALG> S;
                     f4 unused[D];
-                    block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, S, unused);
-                    block_backward<ALG, MULTI>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, in_lds, MT, mt, lane, gy);
+                    block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, GT, S, unused);
+                    block_backward<ALG, MULTI>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, in_lds, MT, mt, lane, GT, gy);
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
                 const int RSo = D * B.CPo + 4;
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                     for (int d = 0; d < D; ++d) gout[d] = splat(0.f);
                     if (mt < B.KKi)
                         linear_from_tile<ALG>(gout, buf_g, RSo, B.CPo, B.KKo, B.pbW1 + (size_t)mt * G * B.KKo * 64, lane);
-                    tile_sync<MULTI>();
+                    tile_sync<MULTI>(GT);
                 } else {
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
                     const int Cs0 = io.seg[0].ch;
@@ -286,13 +288,13 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                         }
                     }
                     if constexpr (MODE == MODE_EDGE) {
-                        tile_sync<MULTI>();
+                        tile_sync<MULTI>(GT);
                         if (io.gx[0]) {
                             scatter_rows<ALG, !MULTI>(stage, Cs0 * D, io.dst, row0, io.rows, io.gx[0], 1.0f, tid_rt, nthr_rt);
                             scatter_rows<ALG, false>(stage, Cs0 * D, io.src, row0, io.rows, io.gx[0], -1.0f, tid_rt, nthr_rt);
                         }
                     }
-                    tile_sync<MULTI>();
+                    tile_sync<MULTI>(GT);
                 }
             }
         }
