@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py — simplicial edges/sec (forward + backward) of one shared simplicial
+message-passing layer (EGCL) on MI355X, with its HBM-roofline fraction and the
+reference CPU path timed beside it.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one EGCL layer (edge CEMLP + scatter + node CEMLP), forward + backward
+(gradients w.r.t. h and every parameter; attributes without gradient, hulls-style),
+on synthetic input already resident in HBM.
+
+Workload (BASELINE.json configs[1]): S1 = Cl(3,0), 8 channels,
+10 000 nodes, 100 000 directed adjacencies per GPU, aggr=mean, seeded generator.
+With N > 1 GPUs the adjacency list of an N x 100k-edge complex over the same 10k
+nodes is sharded (100k edges per rank, weak scaling); each step all-reduces the
+per-node aggregate (forward) and [d/dh | edge-model gradients] (backward) over RCCL.
+"""
+import argparse
+import importlib
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = "clifford-group-equivariant-simplicial-message-passing-networks_amd"
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+WORKLOADS = {
+    # name: (metric, channels, nodes, edges per GPU)
+    "S1": ((1.0, 1.0, 1.0), 8, 10_000, 100_000),
+    "S2": ((1.0, 1.0, 1.0), 16, 100_000, 1_000_000),
+    "S3": ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000),
+}
+
+
+def algorithmic_bytes(C, D, A=6, T=3):
+    """algorithmic HBM bytes per edge / per node of each stage."""
+    row, attr, nattr = C * D * 4, A * D * 4, T * D * 4
+    return {
+        "edge_fwd": 8 + 3 * row + attr,
+        "edge_bwd": 8 + 5 * row + attr,
+        "node_fwd": 3 * row + nattr,
+        "node_bwd": 5 * row + nattr,
+    }
+
+
+def make_inputs(metric, C, N, E_total, lo, hi, device):
+    """Seeded S-series generator; returns this rank's shard [lo, hi)."""
+    D = 1 << len(metric)
+    g = torch.Generator().manual_seed(0)
+    edge_index = torch.randint(0, N, (2, E_total), generator=g, dtype=torch.int64)
+    node_types = torch.randint(0, 3, (N,), generator=g)
+    node_attr = torch.zeros(N, 3, D)
+    node_attr[torch.arange(N), node_types, 0] = 1.0            # one-hot type on the scalar blade
+    h = torch.randn(N, C, D, generator=g)
+    ei = edge_index[:, lo:hi].contiguous()
+    edge_attr = torch.cat([node_attr[ei[0]], node_attr[ei[1]]], dim=1)
+    return (h.to(device), ei.to(device), edge_attr.to(device).contiguous(), node_attr.to(device)), \
+           (h, ei, edge_attr, node_attr)
+
+
+def cpu_baseline(metric, C, state, cpu_inputs, reps):
+    """The reference CPU path (oracle restatement, dense-einsum formulation, PyTorch CPU,
+    all host cores) on the same S1 inputs: fwd+bwd, median of `reps` after one warm-up."""
+    from oracle import ref_path as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    alg = O.Algebra(list(metric))
+    h, ei, ea, na = cpu_inputs
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state.items()}
+    times = []
+    for it in range(reps + 1):
+        hh = h.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        y = O.egcl(alg, hh, ei, ea, na, p, aggr="mean")
+        y.backward(torch.ones_like(y))
+        dt = time.perf_counter() - t0
+        for v in p.values():
+            v.grad = None
+        if it > 0:
+            times.append(dt)
+    med = statistics.median(times)
+    return {"value": ei.shape[1] / med, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"full workload ({ei.shape[1]} edges, {h.shape[0]} nodes), fwd+bwd, median of {reps} runs "
+                      f"after 1 warm-up, torch {torch.__version__} CPU threads={cores}, {med:.3f} s per run"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="S1", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = importlib.import_module(PKG)
+    from csmpn_hip import ops, sharded
+
+    metric, C, N, E_per = WORKLOADS[args.workload]
+    D = 1 << len(metric)
+    E_total = E_per * world
+    lo, hi = sharded.shard_bounds(E_total, world, rank)
+    (h, ei, ea, na), cpu_inputs = make_inputs(metric, C, N, E_total, lo, hi, device)
+
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean")
+    state = {k: v.detach().clone() for k, v in layer.named_parameters()}
+    layer = layer.to(device)
+    params = list(layer.parameters())
+    h.requires_grad_(True)
+    gout = torch.ones(N, C, D, device=device)
+
+    if world > 1:
+        sl = sharded.ShardedEGCL(layer)
+        plan = sl.plan(ei, N)
+
+        def step():
+            y = sl(h, plan, ea, na)
+            return torch.autograd.grad(y, [h] + params, gout)
+    else:
+        def step():
+            y = layer(h, ei, ea, na)
+            return torch.autograd.grad(y, [h] + params, gout)
+
+    # warm-up (builds the CSR once, sets kernel attributes)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+
+    use_graph = (world == 1) and not args.no_graph
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as exc:   # capture is an optimisation of the launch path only
+            print(f"[bench] HIP-graph capture unavailable ({type(exc).__name__}: {exc}); launching eagerly",
+                  file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(2):
+        run()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = E_total * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        # ---- per-stage kernel time (HIP events on the launch stream, weights pre-packed)
+        be = ops.HipBackend
+        spec = layer.spec()
+        csr = ops.get_csr(ei, N) if world == 1 else plan.csr
+        deg = csr.deg if world == 1 else plan.deg
+        pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+        hd = h.detach()
+        agg, st_e = be.edge_forward(spec, csr, hd, ea, pe)
+        out, st_n = be.node_forward(spec, deg, hd, agg, na, pn)
+        gh, g_agg, _, _ = be.node_backward(spec, deg, hd, agg, na, pn, gout, False, st_n)
+        stages = {
+            "edge_fwd": lambda: be.edge_forward(spec, csr, hd, ea, pe),
+            "node_fwd": lambda: be.node_forward(spec, deg, hd, agg, na, pn),
+            "node_bwd": lambda: be.node_backward(spec, deg, hd, agg, na, pn, gout, False, st_n),
+            "edge_bwd": lambda: be.edge_backward(spec, csr, hd, ea, pe, g_agg, gh, False, st_e),
+        }
+        reps = max(10, min(args.steps, 50))
+        stage_ms = {}
+        for name, fn in stages.items():
+            fn()
+            torch.cuda.synchronize()
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for a, b in evs:
+                a.record()
+                fn()
+                b.record()
+            torch.cuda.synchronize()
+            stage_ms[name] = statistics.median(a.elapsed_time(b) for a, b in evs)
+        ab = algorithmic_bytes(C, D)
+        units = {"edge_fwd": E_per, "edge_bwd": E_per, "node_fwd": N, "node_bwd": N}
+        dom = max(stage_ms, key=stage_ms.get)
+        alg_bytes = ab[dom] * units[dom]
+        achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
+        roofline = {
+            "bound": "hbm", "kernel": f"cemlp_kernel<{dom}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "layer_bytes_per_edge": round(bytes_per_edge, 1),
+            "layer_frac_of_hbm_roofline": round(value / world * bytes_per_edge / (HBM_PEAK_GBS * 1e9), 5),
+        }
+        result = {
+            "metric": "simplicial edges/sec (fwd+bwd) on Cl(3,0) 8-ch multivectors; % HBM roofline"
+                      if args.workload == "S1" else f"simplicial edges/sec (fwd+bwd), workload {args.workload}",
+            "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: EGCL layer fwd+bwd, Cl{tuple(int(m) for m in metric)}, "
+                                   f"{C} channels, {N} nodes, {E_per} edges/GPU x {world} GPU, aggr=mean, "
+                                   f"edge_attr 6ch, node_attr 3ch",
+                       "launch": "hip-graph replay" if graph is not None else "eager",
+                       "sharding": "edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"
+                                   if world > 1 else "none"},
+            "roofline": roofline,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(metric, C, state, cpu_inputs, args.cpu_reps)
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

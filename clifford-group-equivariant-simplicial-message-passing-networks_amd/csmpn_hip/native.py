@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcsmpn_hip.so")
 
 MAX_BLOCKS = 4
+FLAG_WEIGHTS_PACKED = 1
 
 # every symbol include/csmpn_hip.h declares
 EXPORTS = (
@@ -60,7 +61,7 @@ def _load():
             f"make -C {os.path.join(os.path.dirname(_HERE), 'csrc')})."
         )
     lib = C.CDLL(LIB_PATH)
-    vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
+    vp, i32, i64, sz, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_uint32
     fp = C.POINTER(C.c_float)
     bp, bg = C.POINTER(BlockParams), C.POINTER(BlockGrads)
 
@@ -74,17 +75,17 @@ def _load():
     sig("csmpn_geometric_product_forward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, vp])
     sig("csmpn_geometric_product_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, i64, vp])
     sig("csmpn_cemlp_workspace_bytes", sz, [C.c_int, bp, C.c_int])
-    sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, sz, vp])
-    sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, sz, vp])
+    sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, sz, u32, vp])
+    sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, sz, u32, vp])
     sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp])
     sig("csmpn_egcl_edge_forward", C.c_int,
-        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, sz, vp])
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_edge_backward", C.c_int,
-        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, sz, vp])
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_node_forward", C.c_int,
-        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, sz, vp])
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_node_backward", C.c_int,
-        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, sz, vp])
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_last_error", C.c_char_p, [])
     sig("csmpn_abi_version", C.c_int, [])
     sig("csmpn_build_target", C.c_char_p, [])

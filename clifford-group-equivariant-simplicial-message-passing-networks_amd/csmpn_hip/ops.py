@@ -129,9 +129,10 @@ class _CemlpFn(torch.autograd.Function):
         y = torch.empty(rows, binding.out_features, binding.D, dtype=torch.float32, device=x.device)
         ws = binding.workspace(x.device)
         check(native.lib().csmpn_cemlp_forward(binding.metric_arr, binding.n, binding.params, binding.nblk,
-                                               x.data_ptr(), rows, y.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               x.data_ptr(), rows, y.data_ptr(), ws.data_ptr(), ws.numel(), 0,
                                                _stream(x.device)))
         ctx.binding = binding
+        ctx.ws = ws   # packed weights are reused by backward
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.mask = [p is not None for p in params]
         return y
@@ -146,10 +147,11 @@ class _CemlpFn(torch.autograd.Function):
         binding.bind(params)
         flat, views = binding.new_grads(params, x.device)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        ws = binding.workspace(x.device)
+        ws = ctx.ws
         check(native.lib().csmpn_cemlp_backward(binding.metric_arr, binding.n, binding.params, binding.grads,
                                                 binding.nblk, x.data_ptr(), gy.data_ptr(), x.shape[0], _ptr(gx),
-                                                ws.data_ptr(), ws.numel(), _stream(x.device)))
+                                                ws.data_ptr(), ws.numel(), native.FLAG_WEIGHTS_PACKED,
+                                                _stream(x.device)))
         return (gx, None, *views)
 
 
@@ -217,45 +219,104 @@ class EgclSpec:
         self.residual = 1 if residual else 0
 
 
+class HipBackend:
+    """The four stages of one EGCL layer as C-ABI calls (device tensors in, device tensors out).
+    The sharded layer (csmpn_hip.sharded) composes the same stages with collectives."""
+
+    @staticmethod
+    def build_csr(edge_index, n_nodes):
+        return get_csr(edge_index, n_nodes)
+
+    @staticmethod
+    def edge_forward(spec, csr, h, edge_attr, pe):
+        e = spec.edge
+        e.bind(pe)
+        N, D = h.shape[0], e.D
+        agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
+        ws = e.workspace(h.device)
+        check(native.lib().csmpn_egcl_edge_forward(
+            e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
+            csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(),
+            ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
+        return agg, ws
+
+    @staticmethod
+    def node_forward(spec, deg, h, agg, node_attr, pn):
+        nd = spec.node
+        nd.bind(pn)
+        N, D = h.shape[0], nd.D
+        out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
+        ws = nd.workspace(h.device)
+        check(native.lib().csmpn_egcl_node_forward(
+            nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
+            _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, out.data_ptr(),
+            ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
+        return out, ws
+
+    @staticmethod
+    def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None):
+        """state: the workspace node_forward returned (its packed weights are reused)."""
+        nd = spec.node
+        nd.bind(pn)
+        N, D, dev = h.shape[0], nd.D, h.device
+        _flat, views = nd.new_grads(pn, dev)
+        gh = torch.empty_like(h)
+        g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
+        g_na = torch.empty_like(node_attr) if (node_attr is not None and want_gna) else None
+        ws = state if state is not None else nd.workspace(dev)
+        flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
+        check(native.lib().csmpn_egcl_node_backward(
+            nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
+            _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, gout.data_ptr(),
+            gh.data_ptr(), g_agg.data_ptr(), _ptr(g_na), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
+        return gh, g_agg, g_na, views
+
+    @staticmethod
+    def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None):
+        """gh is accumulated in place (+= scatter of +-d/d(h_i - h_j))."""
+        e = spec.edge
+        e.bind(pe)
+        N, dev = h.shape[0], h.device
+        _flat, views = e.new_grads(pe, dev)
+        g_ea = torch.empty_like(edge_attr) if (edge_attr is not None and want_gea) else None
+        ws = state if state is not None else e.workspace(dev)
+        flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
+        check(native.lib().csmpn_egcl_edge_backward(
+            e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
+            csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(),
+            gh.data_ptr(), _ptr(g_ea), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
+        return g_ea, views
+
+
+def _check_egcl_inputs(spec, csr, h, edge_attr, node_attr, n_edges):
+    D = spec.edge.D
+    if h.dim() != 3 or h.shape[1] != spec.C or h.shape[2] != D:
+        raise RuntimeError(f"h must be [N, {spec.C}, {D}], got {tuple(h.shape)}")
+    if (edge_attr is None) != (spec.A == 0) or (node_attr is None) != (spec.T == 0):
+        raise RuntimeError("edge_attr/node_attr presence does not match edge_attr_features/node_attr_features")
+    if edge_attr is not None and tuple(edge_attr.shape) != (n_edges, spec.A, D):
+        raise RuntimeError(f"edge_attr must be [{n_edges}, {spec.A}, {D}], got {tuple(edge_attr.shape)}")
+    if node_attr is not None and tuple(node_attr.shape) != (h.shape[0], spec.T, D):
+        raise RuntimeError(f"node_attr must be [{h.shape[0]}, {spec.T}, {D}], got {tuple(node_attr.shape)}")
+
+
 class _EgclFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, edge_attr, node_attr, spec: EgclSpec, csr: Csr, *params):
         _require_device(h, "EGCL input h")
-        lib = native.lib()
-        e, nd = spec.edge, spec.node
-        N, D = h.shape[0], e.D
-        if h.dim() != 3 or h.shape[1] != spec.C or h.shape[2] != D:
-            raise RuntimeError(f"h must be [N, {spec.C}, {D}], got {tuple(h.shape)}")
-        if (edge_attr is None) != (spec.A == 0) or (node_attr is None) != (spec.T == 0):
-            raise RuntimeError("edge_attr/node_attr presence does not match edge_attr_features/node_attr_features")
+        _check_egcl_inputs(spec, csr, h, edge_attr, node_attr, csr.n_edges)
         h = h.contiguous()
         if edge_attr is not None:
             _require_device(edge_attr, "edge_attr")
             edge_attr = edge_attr.contiguous()
-            if tuple(edge_attr.shape) != (csr.n_edges, spec.A, D):
-                raise RuntimeError(f"edge_attr must be [{csr.n_edges}, {spec.A}, {D}], got {tuple(edge_attr.shape)}")
         if node_attr is not None:
             _require_device(node_attr, "node_attr")
             node_attr = node_attr.contiguous()
-            if tuple(node_attr.shape) != (N, spec.T, D):
-                raise RuntimeError(f"node_attr must be [{N}, {spec.T}, {D}], got {tuple(node_attr.shape)}")
-        ne = e.nblk * NP
+        ne = spec.edge.nblk * NP
         pe, pn = params[:ne], params[ne:]
-        e.bind(pe)
-        nd.bind(pn)
-        st = _stream(h.device)
-        agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
-        ws = e.workspace(h.device)
-        check(lib.csmpn_egcl_edge_forward(e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C,
-                                          _ptr(edge_attr), spec.A, csr.perm.data_ptr(), csr.src.data_ptr(),
-                                          csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(),
-                                          ws.numel(), st))
-        out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
-        ws2 = nd.workspace(h.device)
-        check(lib.csmpn_egcl_node_forward(nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C,
-                                          agg.data_ptr(), spec.O, _ptr(node_attr), spec.T, csr.deg.data_ptr(),
-                                          spec.mean, spec.residual, N, out.data_ptr(), ws2.data_ptr(), ws2.numel(), st))
-        ctx.spec, ctx.csr = spec, csr
+        agg, st_e = HipBackend.edge_forward(spec, csr, h, edge_attr, pe)
+        out, st_n = HipBackend.node_forward(spec, csr.deg, h, agg, node_attr, pn)
+        ctx.spec, ctx.csr, ctx.st_e, ctx.st_n = spec, csr, st_e, st_n
         ctx.has_ea, ctx.has_na = edge_attr is not None, node_attr is not None
         ctx.mask = [p is not None for p in params]
         saved = [h, agg]
@@ -268,9 +329,7 @@ class _EgclFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        lib = native.lib()
         spec, csr = ctx.spec, ctx.csr
-        e, nd = spec.edge, spec.node
         saved = list(ctx.saved_tensors)
         h, agg = saved[0], saved[1]
         pos = 2
@@ -281,31 +340,13 @@ class _EgclFn(torch.autograd.Function):
             node_attr = saved[pos]; pos += 1
         it = iter(saved[pos:])
         params = [next(it) if m else None for m in ctx.mask]
-        ne = e.nblk * NP
+        ne = spec.edge.nblk * NP
         pe, pn = params[:ne], params[ne:]
-        e.bind(pe)
-        nd.bind(pn)
-        N, D = h.shape[0], e.D
-        dev = h.device
-        st = _stream(dev)
         gout = gout.contiguous()
-        # one zeroed buffer for all parameter gradients of both CEMLPs
-        flat_e, views_e = e.new_grads(pe, dev)
-        flat_n, views_n = nd.new_grads(pn, dev)
-        gh = torch.empty_like(h)
-        g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
-        g_na = torch.empty_like(node_attr) if (ctx.has_na and ctx.needs_input_grad[2]) else None
-        g_ea = torch.empty_like(edge_attr) if (ctx.has_ea and ctx.needs_input_grad[1]) else None
-        ws2 = nd.workspace(dev)
-        check(lib.csmpn_egcl_node_backward(nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C,
-                                           agg.data_ptr(), spec.O, _ptr(node_attr), spec.T, csr.deg.data_ptr(),
-                                           spec.mean, spec.residual, N, gout.data_ptr(), gh.data_ptr(),
-                                           g_agg.data_ptr(), _ptr(g_na), ws2.data_ptr(), ws2.numel(), st))
-        ws = e.workspace(dev)
-        check(lib.csmpn_egcl_edge_backward(e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C,
-                                           _ptr(edge_attr), spec.A, csr.perm.data_ptr(), csr.src.data_ptr(),
-                                           csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(), gh.data_ptr(),
-                                           _ptr(g_ea), ws.data_ptr(), ws.numel(), st))
+        gh, g_agg, g_na, views_n = HipBackend.node_backward(spec, csr.deg, h, agg, node_attr, pn, gout,
+                                                            ctx.needs_input_grad[2], ctx.st_n)
+        g_ea, views_e = HipBackend.edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, ctx.needs_input_grad[1],
+                                                 ctx.st_e)
         return (gh, g_ea, g_na, None, None, *views_e, *views_n)
 
 

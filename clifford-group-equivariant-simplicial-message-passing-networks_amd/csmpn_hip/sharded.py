@@ -1,0 +1,122 @@
+"""Edge-sharded EGCL over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference never shards a layer (its only multi-GPU mode is whole-model DDP,
+csmpn/md17.py:15-20); this is the partitioning BASELINE.json's north_star names:
+
+  * the edge / simplex-adjacency list is split into contiguous shards, one per rank;
+    node features h, node_attr and all parameters are replicated;
+  * forward: every rank runs the fused edge kernel on its shard -> partial
+    agg[N, O, D]; ONE all-reduce (sum) over the per-node aggregated features; the
+    node update then runs replicated (identical on every rank);
+  * backward: node backward replicated; edge backward on the shard -> partial
+    d/dh[N, C, D] and partial edge-model parameter gradients; ONE all-reduce over
+    [d/dh | edge-model gradients] packed in a single buffer.
+  * mean aggregation uses the GLOBAL in-degree (all-reduced once per complex).
+
+The data path of a shard has no other exchange step. The compute backend is
+injectable so that the collective plumbing is testable on CPU with gloo (tests
+inject the oracle there); the default backend is the HIP C-ABI.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_bounds(n_edges: int, world: int, rank: int):
+    """Contiguous, balanced shard [lo, hi) of the edge list for `rank`."""
+    base, rem = divmod(n_edges, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class ShardPlan:
+    """Per-complex state of one rank: local CSR + global in-degree."""
+
+    def __init__(self, edge_index_local, n_nodes, backend=ops.HipBackend, group=None):
+        self.csr = backend.build_csr(edge_index_local, n_nodes)
+        deg = self.csr.deg.clone()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
+        self.deg = deg
+        self.n_nodes = n_nodes
+
+
+class _ShardedEgclFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, edge_attr, node_attr, spec, plan: ShardPlan, backend, group, *params):
+        h = h.contiguous()
+        ne = spec.edge.nblk * ops.NP
+        pe, pn = params[:ne], params[ne:]
+        agg, st_e = backend.edge_forward(spec, plan.csr, h, edge_attr, pe)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=group)
+        out, st_n = backend.node_forward(spec, plan.deg, h, agg, node_attr, pn)
+        ctx.st_e, ctx.st_n = st_e, st_n
+        ctx.spec, ctx.plan, ctx.backend, ctx.group = spec, plan, backend, group
+        ctx.has_ea, ctx.has_na = edge_attr is not None, node_attr is not None
+        ctx.mask = [p is not None for p in params]
+        saved = [h, agg] + ([edge_attr] if ctx.has_ea else []) + ([node_attr] if ctx.has_na else [])
+        ctx.save_for_backward(*saved, *[p for p in params if p is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        spec, plan, backend, group = ctx.spec, ctx.plan, ctx.backend, ctx.group
+        saved = list(ctx.saved_tensors)
+        h, agg = saved[0], saved[1]
+        pos = 2
+        edge_attr = node_attr = None
+        if ctx.has_ea:
+            edge_attr = saved[pos]; pos += 1
+        if ctx.has_na:
+            node_attr = saved[pos]; pos += 1
+        it = iter(saved[pos:])
+        params = [next(it) if m else None for m in ctx.mask]
+        ne = spec.edge.nblk * ops.NP
+        pe, pn = params[:ne], params[ne:]
+        gout = gout.contiguous()
+        gh_node, g_agg, g_na, views_n = backend.node_backward(spec, plan.deg, h, agg, node_attr, pn, gout,
+                                                              ctx.needs_input_grad[2], ctx.st_n)
+        # partial d/dh of this shard starts from zero so that the all-reduce sums shards only
+        gh_edge = torch.zeros_like(h)
+        g_ea, views_e = backend.edge_backward(spec, plan.csr, h, edge_attr, pe, g_agg, gh_edge,
+                                              ctx.needs_input_grad[1], ctx.st_e)
+        if dist.is_initialized() and dist.get_world_size(group) > 1:
+            # one collective: [d/dh | edge-model parameter gradients]
+            pieces = [gh_edge.reshape(-1)] + [v.reshape(-1) for v in views_e if v is not None]
+            packed = torch.cat(pieces)
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+            off = gh_edge.numel()
+            gh_edge = packed[:off].view_as(h)
+            out_views = []
+            for v in views_e:
+                if v is None:
+                    out_views.append(None)
+                else:
+                    out_views.append(packed[off:off + v.numel()].view(v.shape))
+                    off += v.numel()
+            views_e = out_views
+        gh = gh_node + gh_edge
+        return (gh, g_ea, g_na, None, None, None, None, *views_e, *views_n)
+
+
+class ShardedEGCL(torch.nn.Module):
+    """Wraps an EGCL module; forward takes this rank's shard of the edge list."""
+
+    def __init__(self, layer, backend=ops.HipBackend, group=None):
+        super().__init__()
+        self.layer = layer
+        self.backend = backend
+        self.group = group
+
+    def plan(self, edge_index_local, n_nodes) -> ShardPlan:
+        return ShardPlan(edge_index_local, n_nodes, self.backend, self.group)
+
+    def forward(self, h, plan: ShardPlan, edge_attr_local=None, node_attr=None):
+        layer = self.layer
+        params = layer.edge_model.flat_params() + layer.node_model.flat_params()
+        return _ShardedEgclFn.apply(h, edge_attr_local, node_attr, layer.spec(), plan, self.backend, self.group,
+                                    *params)

@@ -448,13 +448,13 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,
-                        int64_t rows, float* y, void* workspace, size_t workspace_bytes, void* stream) {
+                        int64_t rows, float* y, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan);
     if (rc) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
@@ -465,13 +465,13 @@ int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* bl
 
 int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
                          int n_blocks, const float* x, const float* gy, int64_t rows, float* gx, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
     int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
     if (rc) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
@@ -503,7 +503,7 @@ int csmpn_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* pe
 int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
                             int32_t channels, const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                             const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N, float* agg,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
@@ -514,7 +514,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false,
                        blocks[n_blocks - 1].out_features * D, plan);
     if (rc) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
@@ -530,7 +530,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
                              const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                              const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N,
                              const float* g_agg, float* gh, float* g_edge_attr, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
@@ -539,7 +539,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     Plan plan;
     int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
     if (rc) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
@@ -573,7 +573,7 @@ static int node_io(const csmpn_block_params* blocks, int n_blocks, const float* 
 int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
                             int32_t channels, const float* agg, int32_t agg_channels, const float* node_attr,
                             int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr, int32_t residual,
-                            int64_t N, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+                            int64_t N, float* out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     RowIO io;
@@ -582,7 +582,7 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan))) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     io.y = out; io.resid = residual ? h : nullptr;
     return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream);
 }
@@ -592,7 +592,7 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
                              const float* agg, int32_t agg_channels, const float* node_attr, int32_t attr_channels,
                              const int32_t* in_degree, int32_t mean_aggr, int32_t residual, int64_t N,
                              const float* g_out, float* gh, float* g_agg, float* g_node_attr, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     RowIO io;
@@ -601,7 +601,7 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan))) return rc;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0;
     return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream);

@@ -47,6 +47,11 @@ extern "C" {
 #define CSMPN_ERR_INVALID 2
 #define CSMPN_ERR_HIP 3
 
+/* flags of the compute entry points */
+#define CSMPN_FLAG_WEIGHTS_PACKED 1u /* workspace already holds this CEMLP's packed weights
+                                       (left there by an earlier call with the same parameters):
+                                       skip the pack kernel */
+
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
 typedef struct csmpn_block_params {
@@ -106,19 +111,20 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
 int csmpn_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
                         const float* x, int64_t rows, float* y, void* workspace, size_t workspace_bytes,
-                        void* stream);
+                        uint32_t flags, void* stream);
 
 /* gx[rows, I_0, D] = d<gy,y>/dx (overwritten; may be NULL), grads += d/dparams.
  * Recomputes the forward in-kernel from x. */
 int csmpn_cemlp_backward(const float* metric_host, int n, const csmpn_block_params* blocks,
                          const csmpn_block_grads* grads, int n_blocks, const float* x, const float* gy,
-                         int64_t rows, float* gx, void* workspace, size_t workspace_bytes, void* stream);
+                         int64_t rows, float* gx, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* One-time per complex: sort the E directed adjacencies by target.
  * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
  * Outputs (device): perm[E] (sorted position -> original edge id), src_sorted[E],
  * dst_sorted[E] (int32), in_degree[N] (int32), row_ptr[N+1] (int32).
- * scratch: N+1 int32. The order inside one target's segment is unspecified. */
+ * scratch: N+1 int32. Inside one target's segment the edges keep ascending original
+ * id, so the result (and the summation order downstream) is deterministic. */
 int csmpn_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
                     int32_t* src_sorted, int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr,
                     int32_t* scratch, void* stream);
@@ -132,7 +138,7 @@ int csmpn_egcl_edge_forward(const float* metric_host, int n, const csmpn_block_p
                             const float* h, int32_t channels, const float* edge_attr, int32_t attr_channels,
                             const int32_t* perm, const int32_t* src_sorted, const int32_t* dst_sorted,
                             int64_t n_edges, int64_t n_nodes, float* agg, void* workspace,
-                            size_t workspace_bytes, void* stream);
+                            size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Backward of the above. g_agg [N,O,D] is d/d(agg) (already divided by the degree
  * for aggr=mean). gh [N,C,D] += (scatter of +g to dst, -g to src);
@@ -142,7 +148,7 @@ int csmpn_egcl_edge_backward(const float* metric_host, int n, const csmpn_block_
                              const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                              const int32_t* src_sorted, const int32_t* dst_sorted, int64_t n_edges,
                              int64_t n_nodes, const float* g_agg, float* gh, float* g_edge_attr,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* EGCL update (cegnn_utils.py:264-275):
  *   out[v] = (residual ? h[v] : 0) + NodeCEMLP(cat_c[h[v], agg[v] * s_v, node_attr[v]])
@@ -151,7 +157,7 @@ int csmpn_egcl_node_forward(const float* metric_host, int n, const csmpn_block_p
                             const float* h, int32_t channels, const float* agg, int32_t agg_channels,
                             const float* node_attr, int32_t attr_channels, const int32_t* in_degree,
                             int32_t mean_aggr, int32_t residual, int64_t n_nodes, float* out,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Backward of the above: gh [N,C,D] (overwritten) = d/dh incl. residual,
  * g_agg [N,O,D] (overwritten) = d/d(agg) incl. the mean scale,
@@ -161,7 +167,7 @@ int csmpn_egcl_node_backward(const float* metric_host, int n, const csmpn_block_
                              const float* agg, int32_t agg_channels, const float* node_attr,
                              int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr,
                              int32_t residual, int64_t n_nodes, const float* g_out, float* gh, float* g_agg,
-                             float* g_node_attr, void* workspace, size_t workspace_bytes, void* stream);
+                             float* g_node_attr, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Last error message of the calling thread (never NULL). */
 const char* csmpn_last_error(void);

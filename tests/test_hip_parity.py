@@ -239,7 +239,7 @@ def test_scatter_linearity_full_size(pkg):
         eas = ea[sel].contiguous()
         native.check(native.lib().csmpn_egcl_edge_forward(
             e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), C, eas.data_ptr(), 6, csr.perm.data_ptr(),
-            csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(), ws.numel(),
+            csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(), ws.numel(), 0,
             torch.cuda.current_stream().cuda_stream))
         return agg
     idx = torch.arange(E, device=dev())
