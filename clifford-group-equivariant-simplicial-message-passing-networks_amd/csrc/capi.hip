@@ -68,15 +68,15 @@ int n_paths(AlgId id) {
     }
 }
 
-hipError_t launch_cemlp(AlgId id, int mode, bool multi, bool bwd, unsigned grid, unsigned block, size_t lds,
+hipError_t launch_cemlp(AlgId id, int mode, int var, bool bwd, unsigned grid, unsigned block, size_t lds,
                         hipStream_t st, const DevCemlp& C, const RowIO& io) {
     switch (id) {
-        case ALG_N2: return launch_cemlp_n2(mode, multi, bwd, grid, block, lds, st, C, io);
-        case ALG_N3: return launch_cemlp_n3(mode, multi, bwd, grid, block, lds, st, C, io);
-        case ALG_N4: return launch_cemlp_n4(mode, multi, bwd, grid, block, lds, st, C, io);
-        case ALG_N5: return launch_cemlp_n5(mode, multi, bwd, grid, block, lds, st, C, io);
-        case ALG_N5M: return launch_cemlp_n5m(mode, multi, bwd, grid, block, lds, st, C, io);
-        case ALG_N4M: return launch_cemlp_n4m(mode, multi, bwd, grid, block, lds, st, C, io);
+        case ALG_N2: return launch_cemlp_n2(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N3: return launch_cemlp_n3(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N4: return launch_cemlp_n4(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N5: return launch_cemlp_n5(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N5M: return launch_cemlp_n5m(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N4M: return launch_cemlp_n4m(mode, var, bwd, grid, block, lds, st, C, io);
         default: return hipErrorInvalidValue;
     }
 }
@@ -129,7 +129,7 @@ struct Plan {
     unsigned threads;
     size_t lds_bytes;
     unsigned grid_cap;    // workgroups that fit on the chip at once
-    bool multi;
+    int var;              // VAR_WAVE / VAR_GROUP / VAR_GLOBAL
 };
 
 // LDS/global floats of one 16-row tile's buffers
@@ -157,8 +157,36 @@ TileLayout tile_layout(int D, const csmpn_block_params* blocks, int nblk, bool b
     L.total = off;
     return L;
 }
+struct Choice { int var, rt, wgs; bool mirror; };
+// backward kernels are built for 256 threads (512 VGPRs), forward for 512 threads
+Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, bool bwd) {
+    const int max_rt = ((bwd ? 4 : 8) / MT) > 0 ? (bwd ? 4 : 8) / MT : 1;
+    auto fit = [&](size_t mbytes, int& rt_out, int& wgs_out) {
+        int best_waves = 0;
+        for (int wgs = 1; wgs <= 2; ++wgs) {
+            const size_t budget = (size_t)kMaxLdsBytes / wgs;
+            if (budget <= mbytes) continue;
+            int rt = (int)((budget - mbytes) / tile_bytes);
+            if (rt > max_rt) rt = max_rt;
+            if (rt < 1) continue;
+            if (wgs * rt > best_waves) { best_waves = wgs * rt; rt_out = rt; wgs_out = wgs; }
+        }
+        return best_waves > 0;
+    };
+    Choice c{VAR_GLOBAL, 1, 1, false};
+    int rt = 0, wgs = 1;
+    if (fit(mirror_bytes, rt, wgs)) {
+        c.var = MT > 1 ? VAR_GROUP : VAR_WAVE; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
+        return c;
+    }
+    if (fit(0, rt, wgs)) {   // tiles fit, the gradient mirror does not
+        c.var = VAR_GROUP_NM; c.rt = rt; c.wgs = wgs; c.mirror = false;
+        return c;
+    }
+    c.rt = (4 / MT) > 0 ? 4 / MT : 1;
+    return c;
+}
 constexpr unsigned kGlobalTileGrid = 256;   // workgroups when the tiles live in global scratch
-inline int global_tile_rt(int MT) { int r = 4 / MT; return r < 1 ? 1 : r; }
 
 size_t packed_f4_count(int G, const csmpn_block_params* blocks, int nblk) {
     size_t tot = 0;
@@ -196,9 +224,8 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         maxCPo = rup(b.out_features, 4) > maxCPo ? rup(b.out_features, 4) : maxCPo;
     }
     const int MT = cdiv(maxO, 16);
-    if (MT > 8) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 128 not supported", maxO);
+    if (MT > 4) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 64 not supported", maxO);
     C.MT = MT;
-    plan.multi = MT > 1;
 
     const size_t need = packed_f4_count(G, blocks, nblk) * sizeof(f4);
     if (workspace_bytes < need || !workspace) return fail(CSMPN_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need);
@@ -251,40 +278,23 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     C.off_red = L.off_red; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
 
-    // choose row tiles per workgroup / workgroups per CU
-    const int max_rt = 8 / MT;
-    int best_rt = 0, best_wgs = 1, best_mirror = 0;
-    for (int use_mirror = (bwd ? 1 : 0); use_mirror >= 0 && best_rt == 0; --use_mirror) {
-        const size_t mbytes = use_mirror ? (size_t)mirror * 4 : 0;
-        int best_waves = 0;
-        for (int wgs = 1; wgs <= 2; ++wgs) {
-            const size_t budget = (size_t)kMaxLdsBytes / wgs;
-            if (budget <= mbytes) continue;
-            int rt = (int)((budget - mbytes) / tile_bytes);
-            if (rt > max_rt) rt = max_rt;
-            if (rt < 1) continue;
-            const int waves = wgs * rt * MT;
-            if (waves > best_waves) { best_waves = waves; best_rt = rt; best_wgs = wgs; best_mirror = use_mirror; }
-        }
-    }
-    if (best_rt > 0) {
-        C.RT = best_rt;
-        C.grads_in_lds = best_mirror;
-        C.mirror_floats = best_mirror ? mirror : 0;
+    // choose the storage variant, row tiles per workgroup and workgroups per CU
+    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, bwd);
+    C.RT = ch.rt;
+    plan.var = ch.var;
+    C.grads_in_lds = ch.mirror ? 1 : 0;
+    C.mirror_floats = ch.mirror ? mirror : 0;
+    if (ch.var != VAR_GLOBAL) {
         C.gtiles = nullptr;
-        plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)best_rt * tile_bytes;
-        plan.grid_cap = 256u * (unsigned)best_wgs;
+        plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)ch.rt * tile_bytes;
+        plan.grid_cap = 256u * (unsigned)ch.wgs;
     } else {
         // tiles too large for the LDS: keep them in a global scratch behind the packed weights
-        C.RT = global_tile_rt(MT);
-        const bool mfit = bwd && (size_t)mirror * 4 <= (size_t)kMaxLdsBytes;
-        C.grads_in_lds = mfit ? 1 : 0;
-        C.mirror_floats = mfit ? mirror : 0;
         const size_t scratch = (size_t)kGlobalTileGrid * C.RT * tile_bytes;
         if (workspace_bytes < need + scratch)
             return fail(CSMPN_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need + scratch);
         C.gtiles = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + need);
-        plan.lds_bytes = (size_t)C.mirror_floats * 4;
+        plan.lds_bytes = 0;
         plan.grid_cap = kGlobalTileGrid;
     }
     plan.threads = (unsigned)(C.RT * MT * 64);
@@ -304,7 +314,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, hi
     const long ntiles = (io.rows + 15) / 16;
     long grid = (ntiles + plan.C.RT - 1) / plan.C.RT;
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
-    HIP_TRY(launch_cemlp(id, mode, plan.multi, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
+    HIP_TRY(launch_cemlp(id, mode, plan.var, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
     return CSMPN_OK;
 }
 
@@ -441,9 +451,14 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
     int maxO = 0;
     for (int k = 0; k < n_blocks; ++k) maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
     const int D = 1 << n, MT = cdiv(maxO, 16);
+    // worst case over the entry points: backward layout with the edge-forward staging row
     const TileLayout L = tile_layout(D, blocks, n_blocks, true, blocks[n_blocks - 1].out_features * D);
-    if ((size_t)L.total * 4 > (size_t)kMaxLdsBytes)   // tiles spill to a global scratch (see make_plan)
-        bytes += (size_t)kGlobalTileGrid * global_tile_rt(MT) * L.total * 4;
+    const Choice ch = choose_variant(MT, (size_t)L.total * 4, 0, true);
+    const Choice chf = choose_variant(MT, (size_t)L.total * 4, 0, false);
+    if (ch.var == VAR_GLOBAL || chf.var == VAR_GLOBAL) {
+        const int rt = ch.rt > chf.rt ? ch.rt : chf.rt;
+        bytes += (size_t)kGlobalTileGrid * rt * L.total * 4;
+    }
     return bytes;
 }
 

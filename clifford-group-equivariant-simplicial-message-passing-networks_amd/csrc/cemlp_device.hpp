@@ -27,6 +27,9 @@ namespace csmpn {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define CSMPN_DEV __device__ __forceinline__
+// stop the instruction scheduler from moving code across a phase boundary (keeps the live
+// register set of one phase from overlapping the next one's)
+#define CSMPN_PHASE() __builtin_amdgcn_sched_barrier(0)
 
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
 constexpr float kEps = 1e-6f;        // cegnn_utils.py:5
@@ -126,28 +129,58 @@ CSMPN_DEV float quarters_sum(float v) {
     v += __shfl_xor(v, 32);
     return v;
 }
-// Accuracy: the parity bar is 1e-5 relative against the reference's fp32 CPU path, so
-// division and exp are the correctly-rounded / <=1ulp forms by default; -DCSMPN_FAST_MATH
-// switches to v_rcp_f32 / v_exp_f32 approximations (measured: up to 1.1e-5 on small grads).
+// Accuracy: the parity bar is 1e-5 relative against the reference's fp32 CPU path. The
+// hardware approximations (v_rcp_f32, v_exp_f32, v_rsq_f32: ~1 ulp) are each refined by one
+// Newton / compensation step (2-4 FMAs), which brings them to <=1 ulp of the exact value at
+// a fraction of the IEEE division / expf / sqrtf sequences. -DCSMPN_FAST_MATH drops the
+// refinement (measured: up to 1.1e-5 on small gradients, i.e. over the bar).
 #ifdef CSMPN_FAST_MATH
 CSMPN_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-CSMPN_DEV float sigmoidf(float x) { return fast_rcp(1.0f + __expf(-x)); }
+CSMPN_DEV float exp_neg(float x) { return __builtin_amdgcn_exp2f(-1.44269504088896340736f * x); }
+CSMPN_DEV float sqrt_pos(float x) { return __builtin_amdgcn_sqrtf(x); }
 #else
-CSMPN_DEV float fast_rcp(float x) { return 1.0f / x; }
-CSMPN_DEV float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+CSMPN_DEV float fast_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(r, __builtin_fmaf(-x, r, 1.0f), r);
+}
+// exp(-x) = 2^(t + tl) with t = fl(-x*L), tl = product error + x*(log2e - L)
+CSMPN_DEV float exp_neg(float x) {
+    const float L = 1.44269502162933349609375f, Llo = 1.925963033500011e-08f;
+    const float t = -x * L;
+    const float tl = __builtin_fmaf(-x, L, -t) - x * Llo;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(e, tl * 0.693147180559945309417f, e);
+}
+// sqrt for x >= ~1e-16 (never denormal here): rsq + one Newton step
+CSMPN_DEV float sqrt_pos(float x) {
+    const float r = __builtin_amdgcn_rsqf(x);
+    const float s = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * r, s);
+}
 #endif
+CSMPN_DEV float sigmoidf(float x) { return fast_rcp(1.0f + exp_neg(x)); }
 CSMPN_DEV f4 rcp4(f4 x) { return f4{fast_rcp(x.x), fast_rcp(x.y), fast_rcp(x.z), fast_rcp(x.w)}; }
 CSMPN_DEV f4 sigmoid4(f4 x) { return f4{sigmoidf(x.x), sigmoidf(x.y), sigmoidf(x.z), sigmoidf(x.w)}; }
-CSMPN_DEV f4 sqrt4(f4 x) { return f4{__builtin_sqrtf(x.x), __builtin_sqrtf(x.y), __builtin_sqrtf(x.z), __builtin_sqrtf(x.w)}; }
+CSMPN_DEV f4 sqrt4(f4 x) { return f4{sqrt_pos(x.x), sqrt_pos(x.y), sqrt_pos(x.z), sqrt_pos(x.w)}; }
 // (q^2 + 1e-16)^(1/4)  (cliffordalgebra.py:148-149)
 CSMPN_DEV f4 smooth_abs_sqrt4(f4 q) { return sqrt4(sqrt4(q * q + kSmooth)); }
 CSMPN_DEV f4 splat(float v) { return f4{v, v, v, v}; }
 
-// GT (runtime, uniform): the tile buffers live in global memory (configurations whose
-// tiles exceed the LDS); then every exchange is a workgroup barrier + fence.
-template <bool MULTI>
-CSMPN_DEV void tile_sync(bool GT) {
-    if (MULTI || GT) {
+// Storage variants of the row-tile buffers (compile time, so that the LDS variants use
+// pure LDS addressing: ds_* instructions instead of flat_*):
+//   VAR_WAVE      one wave owns a row tile; buffers + gradient mirror in LDS; no barriers
+//   VAR_GROUP     MT waves share a row tile; buffers + mirror in LDS; workgroup barriers
+//   VAR_GROUP_NM  as VAR_GROUP, but the gradient mirror does not fit beside the tiles:
+//                 parameter gradients go to the global accumulators directly
+//   VAR_GLOBAL    buffers in a global scratch (tiles beyond 160 KB of LDS), gradients by
+//                 global atomics, workgroup barriers
+enum { VAR_WAVE = 0, VAR_GROUP = 1, VAR_GROUP_NM = 2, VAR_GLOBAL = 3 };
+template <int VAR> constexpr bool kVarBarrier = VAR != VAR_WAVE;
+template <int VAR> constexpr bool kVarMirror = VAR == VAR_WAVE || VAR == VAR_GROUP;
+
+template <int VAR>
+CSMPN_DEV void tile_sync() {
+    if constexpr (kVarBarrier<VAR>) {
         __syncthreads();
     } else {
         // one wave owns the tile: LDS operations of a wave execute in order, only
@@ -191,9 +224,9 @@ CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int RS, in
 //   gW[o = 16*mt + 4*(l>>4) + v][c = 16*it + (l&15)][g] += sum_{rows, d in g} Gr[row][d][o] * T[row][d][c]
 // A operand = lane-layout gradient (registers), B operand = input-side LDS tile.
 // Accumulates into `dstp` (LDS mirror laid out [g][O][I], or global reference layout).
-template <class ALG>
+template <class ALG, bool dst_is_mirror>
 CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int RS, int CP, int I, int O, int KKin,
-                           int mt, int lane, float* dstp, bool dst_is_mirror, bool has_grades) {
+                           int mt, int lane, float* dstp, bool has_grades) {
     constexpr int D = ALG::D, G = ALG::G;
     const int n = lane & 15, q = lane >> 4;
     for (int it = 0; it < KKin; ++it) {
@@ -283,9 +316,8 @@ template <class ALG>
 struct FwdState {
     f4 y[ALG::D];        // MVLinear output
     f4 gate[ALG::G];     // sigmoid gates of MVSiLU
-    f4 u[ALG::G];        // gate invariants
     f4 R[ALG::D];        // linear_right output
-    f4 qR[ALG::G], nu[ALG::G], invden[ALG::G];
+    f4 invden[ALG::G];   // 1 / (interpolated norm + eps) of NormalizationLayer
     f4 s[ALG::D];        // (left + gp)/sqrt2, input of MVLayerNorm
     f4 qs, nl, invMn;
 };
@@ -319,11 +351,13 @@ CSMPN_DEV void weighted_gp(f4 (&out)[ALG::D], const f4 (&z)[ALG::D], const f4 (&
     });
 }
 
-// backward of weighted_gp: gz, gr accumulate; gw[p] returns per-lane (4-row) sums
+// backward of weighted_gp: gz, gr accumulate; gw[p] is reduced over the tile's rows and
+// added to gw_dst. The left/right operands z = gate*y and r = R*invden are rebuilt per path
+// from the kept forward state instead of being held in registers (64 VGPRs less).
 template <class ALG>
-CSMPN_DEV void weighted_gp_bwd(const f4 (&ggp)[ALG::D], const f4 (&z)[ALG::D], const f4 (&r)[ALG::D],
-                               const float* wrow, f4 (&gz)[ALG::D], f4 (&gr)[ALG::D], float* gw_dst, bool lane0q,
-                               bool cvalid) {
+CSMPN_DEV void weighted_gp_bwd(const f4 (&ggp)[ALG::D], const f4 (&y)[ALG::D], const f4 (&gate)[ALG::G],
+                               const f4 (&R)[ALG::D], const f4 (&invden)[ALG::G], const float* wrow,
+                               f4 (&gz)[ALG::D], f4 (&gr)[ALG::D], float* gw_dst, bool lane0q, bool cvalid) {
     constexpr int P = ALG::P;
     static_for<0, P>([&](auto p) {
         constexpr int gi = ALG::t.path_g[p][0], gj = ALG::t.path_g[p][1], gk = ALG::t.path_g[p][2];
@@ -332,23 +366,26 @@ CSMPN_DEV void weighted_gp_bwd(const f4 (&ggp)[ALG::D], const f4 (&z)[ALG::D], c
         constexpr int k0 = ALG::gstart(gk), nk = ALG::gsize(gk);
         const float w = wrow[p];
         f4 U[ni];    // U[i] = sum_{k,j} sign * ggp[j] * r[k]   (unweighted d/dz)
-        f4 wz[ni];   // w * z[i]
+        f4 zi[ni];   // z[i]
+        f4 rk[nk];   // r[k]
 #pragma unroll
-        for (int t = 0; t < ni; ++t) { U[t] = splat(0.f); wz[t] = w * z[i0 + t]; }
+        for (int t = 0; t < ni; ++t) { U[t] = splat(0.f); zi[t] = gate[gi] * y[i0 + t]; }
+#pragma unroll
+        for (int t = 0; t < nk; ++t) rk[t] = R[k0 + t] * invden[gk];
         static_for<0, ni>([&](auto ii) {
             static_for<0, nk>([&](auto kk) {
                 constexpr int i = i0 + ii, k = k0 + kk;
                 constexpr int j = ALG::t.out[i][k];
                 if constexpr (j >= j0 && j < j0 + nj) {
                     constexpr float sg = float(ALG::t.sign[i][k]);
-                    U[ii] += (sg * ggp[j]) * r[k];
-                    gr[k] += (sg * ggp[j]) * wz[ii];
+                    U[ii] += (sg * ggp[j]) * rk[kk];
+                    gr[k] += (sg * w) * (ggp[j] * zi[ii]);
                 }
             });
         });
         f4 gwv = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < ni; ++t) { gz[i0 + t] += w * U[t]; gwv += z[i0 + t] * U[t]; }
+        for (int t = 0; t < ni; ++t) { gz[i0 + t] += w * U[t]; gwv += zi[t] * U[t]; }
         const float tot = quarters_sum(hsum(gwv));
         if (lane0q && cvalid) atomicAdd(gw_dst + p, tot);
     });
@@ -377,9 +414,9 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 // block forward. Input tile in LDS (xin), output in lane layout (out) for this wave's
 // channel tile. zbuf: LDS tile for the gated activations (feeds linear_left/right).
 // red: LDS scratch [MT][16] floats for cross-wave LayerNorm sums (MULTI only).
-template <class ALG, bool MULTI>
+template <class ALG, int VAR>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
-                             float* red, int MT, int mt, int lane, bool GT, FwdState<ALG>& S, f4 (&out)[ALG::D]) {
+                             float* red, int MT, int mt, int lane, FwdState<ALG>& S, f4 (&out)[ALG::D]) {
     constexpr int D = ALG::D, G = ALG::G;
     const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
     const int c = 16 * mt + (lane & 15), q = lane >> 4;
@@ -391,6 +428,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     if (tile_active) linear_from_tile<ALG>(S.y, xin, RSi, B.CPi, B.KKi, B.pfW1 + (size_t)mt * G * B.KKi * 64, lane);
     S.y[0] += lp.b1;
 
+    CSMPN_PHASE();
     // 2. MVSiLU, invariant "mag2" (cegnn_utils.py:76-83)
     f4 z[D];
     static_for<0, G>([&](auto g) {
@@ -405,14 +443,14 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
                 u += qsf<ALG, d> * S.y[d] * S.y[d];
             });
         }
-        S.u[g] = u;
         S.gate[g] = sigmoid4(lp.sa[g] * u + lp.sb[g]);
 #pragma unroll
         for (int t = 0; t < nd; ++t) z[d0 + t] = S.gate[g] * S.y[d0 + t];
     });
     store_tile<ALG>(z, zbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>(GT);
+    tile_sync<VAR>();
 
+    CSMPN_PHASE();
     // 3. linear_right / linear_left (cegnn_utils.py:143-148)
     f4 L[D];
 #pragma unroll
@@ -423,6 +461,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     }
     L[0] += lp.bL;
 
+    CSMPN_PHASE();
     // 4. NormalizationLayer on the right operand (cegnn_utils.py:42-51)
     f4 r[D];
     static_for<0, G>([&](auto g) {
@@ -432,19 +471,19 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
             constexpr int d = d0 + decltype(t)::value;
             qq += qsf<ALG, d> * S.R[d] * S.R[d];
         });
-        S.qR[g] = qq;
-        S.nu[g] = smooth_abs_sqrt4(qq);
-        const f4 m = lp.sg[g] * (S.nu[g] - 1.0f) + 1.0f;
+        const f4 m = lp.sg[g] * (smooth_abs_sqrt4(qq) - 1.0f) + 1.0f;
         S.invden[g] = rcp4(m + kEps);
 #pragma unroll
         for (int t = 0; t < nd; ++t) r[d0 + t] = S.R[d0 + t] * S.invden[g];
     });
 
+    CSMPN_PHASE();
     // 5. steerable geometric product + first-order term (cegnn_utils.py:126-152)
     if (lp.cvalid) weighted_gp<ALG>(L, z, r, B.w + (size_t)c * ALG::P);
 #pragma unroll
     for (int d = 0; d < D; ++d) S.s[d] = L[d] * kInvSqrt2;
 
+    CSMPN_PHASE();
     // 6. MVLayerNorm (cegnn_utils.py:93-96): mean over the channels of the row
     f4 qs = splat(0.f);
     static_for<0, D>([&](auto dd) {
@@ -454,7 +493,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     S.qs = qs;
     S.nl = smooth_abs_sqrt4(qs);
     f4 tot = row16_sum4(lp.cvalid ? S.nl : splat(0.f));
-    if constexpr (MULTI) {
+    if constexpr (kVarBarrier<VAR>) {
         if ((lane & 15) == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * q) = tot;
         __syncthreads();
         tot = splat(0.f);
@@ -470,11 +509,10 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 // block backward: given the forward state S of this tile and gout (lane layout),
 // accumulate all parameter gradients and leave d/d(MVLinear output) in gy (lane
 // layout) AND in the LDS tile gbuf (so the caller can run the transposed MVLinear).
-template <class ALG, bool MULTI>
+template <class ALG, int VAR>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
-                              float* red, float* mirror, bool in_lds, int MT, int mt, int lane, bool GT,
-                              f4 (&gy)[ALG::D]) {
+                              float* red, float* mirror, int MT, int mt, int lane, f4 (&gy)[ALG::D]) {
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P;
     const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
     const int c = 16 * mt + (lane & 15), q = lane >> 4;
@@ -483,17 +521,17 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     const bool cv = lp.cvalid;
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, P, B.w1_sub != 0);
     float* mir = mirror + B.lds_goff;
-    // gradient destinations (LDS mirror or global reference layout)
-    float* d_b1 = in_lds ? mir + mo.b1 : B.gb1;
-    float* d_sa = in_lds ? mir + mo.sa : B.gsa;
-    float* d_sb = in_lds ? mir + mo.sb : B.gsb;
-    float* d_w = in_lds ? mir + mo.w : B.gw;
-    float* d_an = in_lds ? mir + mo.an : B.gan;
-    float* d_bL = in_lds ? mir + mo.bL : B.gbL;
-    float* d_la = in_lds ? mir + mo.la : B.gla;
-    float* d_W1 = in_lds ? mir + mo.W1 : B.gW1;
-    float* d_WR = in_lds ? mir + mo.WR : B.gWR;
-    float* d_WL = in_lds ? mir + mo.WL : B.gWL;
+    // gradient destinations: LDS mirror (flushed once per workgroup) or, in the global-tile
+    // variant, the global reference-layout accumulators directly
+    constexpr bool in_lds = kVarMirror<VAR>;
+    float *d_b1, *d_sa, *d_sb, *d_w, *d_an, *d_bL, *d_la, *d_W1, *d_WR, *d_WL;
+    if constexpr (in_lds) {
+        d_b1 = mir + mo.b1; d_sa = mir + mo.sa; d_sb = mir + mo.sb; d_w = mir + mo.w; d_an = mir + mo.an;
+        d_bL = mir + mo.bL; d_la = mir + mo.la; d_W1 = mir + mo.W1; d_WR = mir + mo.WR; d_WL = mir + mo.WL;
+    } else {
+        d_b1 = B.gb1; d_sa = B.gsa; d_sb = B.gsb; d_w = B.gw; d_an = B.gan;
+        d_bL = B.gbL; d_la = B.gla; d_W1 = B.gW1; d_WR = B.gWR; d_WL = B.gWL;
+    }
 
     // ---- MVLayerNorm backward
     f4 dot = splat(0.f), gla = splat(0.f);
@@ -505,7 +543,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         if (lane0q && cv) atomicAdd(d_la + c, t);
     }
     f4 gMn = row16_sum4(-(lp.la * dot) * S.invMn * S.invMn);
-    if constexpr (MULTI) {
+    if constexpr (kVarBarrier<VAR>) {
         if ((lane & 15) == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * q) = gMn;
         __syncthreads();
         gMn = splat(0.f);
@@ -526,58 +564,60 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         if (lane0q && cv) atomicAdd(d_bL + c, t);
     }
 
+    CSMPN_PHASE();
     // ---- d/dz from linear_left: gz = GL . WL^T ; gWL += GL (x) Z
     store_tile<ALG>(ggp, gbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>(GT);
+    tile_sync<VAR>();
     f4 gz[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gz[d] = splat(0.f);
     if (tile_active) {
         linear_from_tile<ALG>(gz, gbuf, RSo, B.CPo, B.KKo, B.pbWL + (size_t)mt * G * B.KKo * 64, lane);
-        weight_grad<ALG>(ggp, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WL, in_lds, true);
+        weight_grad<ALG, in_lds>(ggp, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WL, true);
     }
 
+    CSMPN_PHASE();
     // ---- geometric product backward
-    f4 z[D], r[D], gr[D];
-    static_for<0, G>([&](auto g) {
-        constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+    f4 gr[D];
 #pragma unroll
-        for (int t = 0; t < nd; ++t) {
-            z[d0 + t] = S.gate[g] * S.y[d0 + t];
-            r[d0 + t] = S.R[d0 + t] * S.invden[g];
-            gr[d0 + t] = splat(0.f);
-        }
-    });
+    for (int d = 0; d < D; ++d) gr[d] = splat(0.f);
     if (tile_active)
-        weighted_gp_bwd<ALG>(ggp, z, r, B.w + (size_t)(cv ? c : 0) * P, gz, gr, d_w + (size_t)(cv ? c : 0) * P, lane0q, cv);
+        weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, B.w + (size_t)(cv ? c : 0) * P, gz, gr,
+                             d_w + (size_t)(cv ? c : 0) * P, lane0q, cv);
 
-    // ---- NormalizationLayer backward -> gR
+    CSMPN_PHASE();
+    // ---- NormalizationLayer backward -> gR (q_g and nu_g are rebuilt from R)
     f4 gR[D];
     static_for<0, G>([&](auto g) {
         constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-        f4 gden = splat(0.f);
-#pragma unroll
-        for (int t = 0; t < nd; ++t) gden -= gr[d0 + t] * r[d0 + t];
-        gden *= S.invden[g];
+        f4 gden = splat(0.f), qR = splat(0.f);
+        static_for<0, nd>([&](auto t) {
+            constexpr int d = d0 + decltype(t)::value;
+            gden -= gr[d] * S.R[d];
+            qR += qsf<ALG, d> * S.R[d] * S.R[d];
+        });
+        gden *= S.invden[g] * S.invden[g];      // d/d(den): -sum gr * R / den^2
+        const f4 nu = smooth_abs_sqrt4(qR);
         {
-            const float t = quarters_sum(hsum(gden * (S.nu[g] - 1.0f))) * lp.sg[g] * (1.0f - lp.sg[g]);
+            const float t = quarters_sum(hsum(gden * (nu - 1.0f))) * lp.sg[g] * (1.0f - lp.sg[g]);
             if (lane0q && cv) atomicAdd(d_an + c * G + g, t);
         }
-        const f4 inu = rcp4(S.nu[g]);
-        const f4 gq = (gden * lp.sg[g]) * (0.5f * S.qR[g]) * (inu * inu * inu);
+        const f4 inu = rcp4(nu);
+        const f4 gq = (gden * lp.sg[g]) * (0.5f * qR) * (inu * inu * inu);
         static_for<0, nd>([&](auto t) {
             constexpr int d = d0 + decltype(t)::value;
             gR[d] = cv ? gr[d] * S.invden[g] + gq * (2.0f * qsf<ALG, d>) * S.R[d] : splat(0.f);
         });
     });
-    tile_sync<MULTI>(GT);   // all reads of gbuf (GL) done
+    tile_sync<VAR>();   // all reads of gbuf (GL) done
     store_tile<ALG>(gR, gbuf, RSo, B.CPo, mt, lane);
-    tile_sync<MULTI>(GT);
+    tile_sync<VAR>();
     if (tile_active) {
         linear_from_tile<ALG>(gz, gbuf, RSo, B.CPo, B.KKo, B.pbWR + (size_t)mt * G * B.KKo * 64, lane);
-        weight_grad<ALG>(gR, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WR, in_lds, true);
+        weight_grad<ALG, in_lds>(gR, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WR, true);
     }
 
+    CSMPN_PHASE();
     // ---- MVSiLU backward -> gy
     static_for<0, G>([&](auto g) {
         constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
@@ -585,8 +625,18 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
 #pragma unroll
         for (int t = 0; t < nd; ++t) ggate += gz[d0 + t] * S.y[d0 + t];
         const f4 gpre = ggate * S.gate[g] * (1.0f - S.gate[g]);
+        f4 u;
+        if constexpr (g == 0) {
+            u = S.y[0];
+        } else {
+            u = splat(0.f);
+            static_for<0, nd>([&](auto t) {
+                constexpr int d = d0 + decltype(t)::value;
+                u += qsf<ALG, d> * S.y[d] * S.y[d];
+            });
+        }
         {
-            const float ta = quarters_sum(hsum(gpre * S.u[g]));
+            const float ta = quarters_sum(hsum(gpre * u));
             const float tb = quarters_sum(hsum(gpre));
             if (lane0q && cv) { atomicAdd(d_sa + c * G + g, ta); atomicAdd(d_sb + c * G + g, tb); }
         }
@@ -603,11 +653,12 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         const float t = quarters_sum(hsum(gy[0]));
         if (lane0q && cv) atomicAdd(d_b1 + c, t);
     }
+    CSMPN_PHASE();
     // ---- MVLinear weight gradient; gy tile to LDS for the transposed MVLinear
-    tile_sync<MULTI>(GT);   // all reads of gbuf (GR) done
+    tile_sync<VAR>();   // all reads of gbuf (GR) done
     store_tile<ALG>(gy, gbuf, RSo, B.CPo, mt, lane);
-    if (tile_active) weight_grad<ALG>(gy, xin, RSi, B.CPi, B.I, B.O, B.KKi, mt, lane, d_W1, in_lds, B.w1_sub != 0);
-    tile_sync<MULTI>(GT);
+    if (tile_active) weight_grad<ALG, in_lds>(gy, xin, RSi, B.CPi, B.I, B.O, B.KKi, mt, lane, d_W1, B.w1_sub != 0);
+    tile_sync<VAR>();
 }
 
 // flush one block's LDS gradient mirror into the global reference-layout accumulators

