@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -56,6 +57,18 @@ AlgId alg_id(const float* metric, int n) {
     return ALG_NONE;
 }
 
+bool has_h2(AlgId id) {
+    switch (id) {
+        case ALG_N2: return has_h2_n2();
+        case ALG_N3: return has_h2_n3();
+        case ALG_N4: return has_h2_n4();
+        case ALG_N5: return has_h2_n5();
+        case ALG_N5M: return has_h2_n5m();
+        case ALG_N4M: return has_h2_n4m();
+        default: return false;
+    }
+}
+
 int n_paths(AlgId id) {
     switch (id) {
         case ALG_N2: return Alg<2, 0u>::P;
@@ -68,15 +81,15 @@ int n_paths(AlgId id) {
     }
 }
 
-hipError_t launch_cemlp(AlgId id, int mode, int var, bool bwd, unsigned grid, unsigned block, size_t lds,
+hipError_t launch_cemlp(AlgId id, int mode, int var, int h, bool bwd, unsigned grid, unsigned block, size_t lds,
                         hipStream_t st, const DevCemlp& C, const RowIO& io) {
     switch (id) {
-        case ALG_N2: return launch_cemlp_n2(mode, var, bwd, grid, block, lds, st, C, io);
-        case ALG_N3: return launch_cemlp_n3(mode, var, bwd, grid, block, lds, st, C, io);
-        case ALG_N4: return launch_cemlp_n4(mode, var, bwd, grid, block, lds, st, C, io);
-        case ALG_N5: return launch_cemlp_n5(mode, var, bwd, grid, block, lds, st, C, io);
-        case ALG_N5M: return launch_cemlp_n5m(mode, var, bwd, grid, block, lds, st, C, io);
-        case ALG_N4M: return launch_cemlp_n4m(mode, var, bwd, grid, block, lds, st, C, io);
+        case ALG_N2: return launch_cemlp_n2(mode, var, h, bwd, grid, block, lds, st, C, io);
+        case ALG_N3: return launch_cemlp_n3(mode, var, h, bwd, grid, block, lds, st, C, io);
+        case ALG_N4: return launch_cemlp_n4(mode, var, h, bwd, grid, block, lds, st, C, io);
+        case ALG_N5: return launch_cemlp_n5(mode, var, h, bwd, grid, block, lds, st, C, io);
+        case ALG_N5M: return launch_cemlp_n5m(mode, var, h, bwd, grid, block, lds, st, C, io);
+        case ALG_N4M: return launch_cemlp_n4m(mode, var, h, bwd, grid, block, lds, st, C, io);
         default: return hipErrorInvalidValue;
     }
 }
@@ -101,25 +114,29 @@ __global__ void pack_weights_kernel(const PackDesc P) {
     int s = 0;
     while (e >= P.seg[s].count) { e -= P.seg[s].count; ++s; }
     const PackSeg& S = P.seg[s];
+    const int H = P.H, NW = 16 / H;
     const int lane = e & 63;
     int rest = e >> 6;
-    // fragment order [n-tile][grade][k-block][lane]
-    const int kk = rest % S.KK; rest /= S.KK;
+    // fragment order [N tile][k-block][row half][grade][lane]
     const int g = rest % P.G; rest /= P.G;
+    const int hp = rest % H; rest /= H;
+    const int kk = rest % S.KK; rest /= S.KK;
     const int nt = rest;
-    const int n = 16 * nt + (lane & 15);
+    const int ncol = lane & 15;
+    const int hcol = H == 1 ? 0 : (ncol >> 3);
+    const int n = NW * nt + (H == 1 ? ncol : (ncol & 7));
     f4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int k = 16 * kk + 4 * (lane >> 4) + r;
         const int o = S.transposed ? k : n, i = S.transposed ? n : k;
         float val = 0.f;
-        if (o < S.O && i < S.I) val = S.has_grades ? S.w[((size_t)o * S.I + i) * P.G + g] : S.w[(size_t)o * S.I + i];
+        if (hcol == hp && o < S.O && i < S.I)
+            val = S.has_grades ? S.w[((size_t)o * S.I + i) * P.G + g] : S.w[(size_t)o * S.I + i];
         v[r] = val;
     }
     S.dst[e] = v;
 }
-
 
 // ----------------------------------------------------------------------------- planning
 struct Plan {
@@ -129,20 +146,23 @@ struct Plan {
     unsigned threads;
     size_t lds_bytes;
     unsigned grid_cap;    // workgroups that fit on the chip at once
-    int var;              // VAR_WAVE / VAR_GROUP / VAR_GLOBAL
+    int var;              // VAR_WAVE / VAR_GROUP / VAR_GROUP_NM / VAR_GLOBAL
+    int H;                // row halves per tile
 };
 
-// LDS/global floats of one 16-row tile's buffers
+// floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
 struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, total; };
-TileLayout tile_layout(int D, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen) {
+TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen) {
     int maxO = 0, maxCPo = 0;
     for (int k = 0; k < nblk; ++k) {
         maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
         maxCPo = rup(blocks[k].out_features, 4) > maxCPo ? rup(blocks[k].out_features, 4) : maxCPo;
     }
-    const int MT = cdiv(maxO, 16);
-    const int sz_in = 16 * (D * rup(blocks[0].in_features, 4) + 4);
-    const int sz_o = 16 * (D * maxCPo + 4);
+    const int R = 16 * H, CS = R * D + 4, NW = 16 / H;
+    const int MT = cdiv(maxO, NW);
+    int sz_in = rup(blocks[0].in_features, 4) * CS;
+    if (bwd && R * blocks[0].in_features * D > sz_in) sz_in = rup(R * blocks[0].in_features * D, 4);  // gx staging
+    const int sz_o = maxCPo * CS;
     TileLayout L;
     int off = 0;
     L.off_in = off; off += sz_in;
@@ -151,7 +171,7 @@ TileLayout tile_layout(int D, const csmpn_block_params* blocks, int nblk, bool b
     L.off_z = off; off += sz_o;
     L.off_g = off;
     int sz_g = bwd ? sz_o : 0;
-    if (stage_rowlen > 0 && 16 * stage_rowlen > sz_g) sz_g = rup(16 * stage_rowlen, 4);
+    if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
     off += sz_g;
     L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
     L.total = off;
@@ -188,13 +208,15 @@ Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, bool bwd) 
 }
 constexpr unsigned kGlobalTileGrid = 256;   // workgroups when the tiles live in global scratch
 
-size_t packed_f4_count(int G, const csmpn_block_params* blocks, int nblk) {
+size_t packed_f4_count(int G, int H, const csmpn_block_params* blocks, int nblk) {
     size_t tot = 0;
+    const int NW = 16 / H;
     for (int k = 0; k < nblk; ++k) {
         const int I = blocks[k].in_features, O = blocks[k].out_features;
-        const size_t KKi = cdiv(I, 16), KKo = cdiv(O, 16);
-        tot += 2 * (size_t)G * KKo * KKi * 64;       // W1 forward + transposed
-        tot += 4 * (size_t)G * KKo * KKo * 64;       // WR, WL forward + transposed
+        const size_t KKi = cdiv(I, 16), KKo = cdiv(O, 16), NTi = cdiv(I, NW), NTo = cdiv(O, NW);
+        const size_t per = (size_t)H * G * 64;
+        tot += per * (NTo * KKi + NTi * KKo);        // W1 forward + transposed
+        tot += per * 4 * NTo * KKo;                  // WR, WL forward + transposed
     }
     return tot;
 }
@@ -203,7 +225,33 @@ int mirror_floats_of(int I, int O, int G, int P, bool sub) {
     return (sub ? G : 1) * O * I + 2 * G * O * O + 3 * O + 3 * O * G + O * P;
 }
 
-// mode/bwd decide the LDS footprint. stage_rowlen: dense staging row length needed in buf_g (edge forward).
+// H is a property of the CEMLP (not of the entry point): forward and backward of one layer
+// share the packed weights, so both must pick the same tile geometry. H = 2 (32-row tiles,
+// 8 lane columns per half) when every width is <= 8 channels, the algebra has the H = 2
+// kernels, and the backward layout still fits at least two row tiles beside the mirror.
+int mirror_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
+    int m = 0;
+    for (int k = 0; k < nblk; ++k)
+        m += rup(mirror_floats_of(blocks[k].in_features, blocks[k].out_features, G, P, blocks[k].lin_subspaces != 0), 4);
+    return m;
+}
+
+int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
+    int maxO = 0;
+    for (int k = 0; k < nblk; ++k) maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
+    if (maxO > 8 || !has_h2(id)) return 1;
+    const int D = 1 << n, G = n + 1;
+    const TileLayout Lb = tile_layout(D, 2, blocks, nblk, true, 0);
+    const TileLayout Lf = tile_layout(D, 2, blocks, nblk, false, blocks[nblk - 1].out_features * D);
+    const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
+    const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, true);
+    const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, false);
+    if (cb.var == VAR_WAVE && cb.rt * cb.wgs >= 2 && cf.var == VAR_WAVE && cf.rt * cf.wgs >= 2) return 2;
+    return 1;
+}
+
+// bwd / stage_rowlen decide the footprint. stage_rowlen: dense staging row length needed in
+// buf_g (edge forward scatter).
 int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads, int nblk,
               void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, Plan& plan) {
     if (nblk < 1 || nblk > CSMPN_MAX_BLOCKS) return fail(CSMPN_ERR_INVALID, "n_blocks=%d not in 1..%d", nblk, CSMPN_MAX_BLOCKS);
@@ -211,7 +259,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     memset(&plan, 0, sizeof(plan));
     DevCemlp& C = plan.C;
     C.nblk = nblk;
-    int maxO = 0, maxCPo = 0;
+    int maxO = 0;
     for (int k = 0; k < nblk; ++k) {
         const csmpn_block_params& b = blocks[k];
         if (b.in_features < 1 || b.out_features < 1) return fail(CSMPN_ERR_INVALID, "block %d: bad feature counts", k);
@@ -221,23 +269,27 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         if (!b.lin_w || !b.silu_a || !b.silu_b || !b.gp_w || !b.norm_a || !b.right_w || !b.left_w || !b.left_b || !b.ln_a)
             return fail(CSMPN_ERR_INVALID, "block %d: null parameter pointer", k);
         maxO = b.out_features > maxO ? b.out_features : maxO;
-        maxCPo = rup(b.out_features, 4) > maxCPo ? rup(b.out_features, 4) : maxCPo;
     }
-    const int MT = cdiv(maxO, 16);
+    const int H = decide_h(id, n, blocks, nblk);
+    const int NW = 16 / H;
+    const int MT = cdiv(maxO, NW);
     if (MT > 4) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 64 not supported", maxO);
     C.MT = MT;
+    C.H = H;
+    plan.H = H;
 
-    const size_t need = packed_f4_count(G, blocks, nblk) * sizeof(f4);
+    const size_t need = packed_f4_count(G, H, blocks, nblk) * sizeof(f4);
     if (workspace_bytes < need || !workspace) return fail(CSMPN_ERR_INVALID, "workspace too small: %zu < %zu", workspace_bytes, need);
     f4* ws = reinterpret_cast<f4*>(workspace);
     PackDesc& PD = plan.P;
     PD.G = G;
+    PD.H = H;
     size_t cursor = 0;
     int mirror = 0;
     auto add_seg = [&](const float* w, int O, int I, int has_grades, int transposed, int NT, int KK) -> const f4* {
         PackSeg& s = PD.seg[PD.nseg++];
         s.w = w; s.dst = ws + cursor; s.O = O; s.I = I; s.has_grades = has_grades; s.transposed = transposed;
-        s.NT = NT; s.KK = KK; s.count = G * NT * KK * 64;
+        s.NT = NT; s.KK = KK; s.count = NT * KK * H * G * 64;
         PD.total += s.count;
         const f4* p = s.dst;
         cursor += (size_t)s.count;
@@ -248,16 +300,17 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         DevBlock& B = C.b[k];
         B.I = b.in_features; B.O = b.out_features;
         B.KKi = cdiv(B.I, 16); B.KKo = cdiv(B.O, 16);
+        B.NTi = cdiv(B.I, NW); B.NTo = cdiv(B.O, NW);
         B.CPi = rup(B.I, 4); B.CPo = rup(B.O, 4);
         B.has_b1 = b.lin_b != nullptr;
         B.w1_sub = b.lin_subspaces ? 1 : 0;
         B.b1 = b.lin_b; B.sa = b.silu_a; B.sb = b.silu_b; B.w = b.gp_w; B.an = b.norm_a; B.bL = b.left_b; B.la = b.ln_a;
-        B.pfW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 0, B.KKo, B.KKi);
-        B.pfWR = add_seg(b.right_w, B.O, B.O, 1, 0, B.KKo, B.KKo);
-        B.pfWL = add_seg(b.left_w, B.O, B.O, 1, 0, B.KKo, B.KKo);
-        B.pbW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 1, B.KKi, B.KKo);
-        B.pbWR = add_seg(b.right_w, B.O, B.O, 1, 1, B.KKo, B.KKo);
-        B.pbWL = add_seg(b.left_w, B.O, B.O, 1, 1, B.KKo, B.KKo);
+        B.pfW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 0, B.NTo, B.KKi);
+        B.pfWR = add_seg(b.right_w, B.O, B.O, 1, 0, B.NTo, B.KKo);
+        B.pfWL = add_seg(b.left_w, B.O, B.O, 1, 0, B.NTo, B.KKo);
+        B.pbW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 1, B.NTi, B.KKo);
+        B.pbWR = add_seg(b.right_w, B.O, B.O, 1, 1, B.NTo, B.KKo);
+        B.pbWL = add_seg(b.left_w, B.O, B.O, 1, 1, B.NTo, B.KKo);
         B.lds_goff = mirror;
         mirror += rup(mirror_floats_of(B.I, B.O, G, P, B.w1_sub), 4);
         if (bwd) {
@@ -273,7 +326,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     plan.pack_f4 = cursor;
 
     // buffers of one row tile (floats)
-    const TileLayout L = tile_layout(D, blocks, nblk, bwd, stage_rowlen);
+    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen);
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
     C.off_red = L.off_red; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
@@ -282,7 +335,6 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, bwd);
     C.RT = ch.rt;
     plan.var = ch.var;
-    C.grads_in_lds = ch.mirror ? 1 : 0;
     C.mirror_floats = ch.mirror ? mirror : 0;
     if (ch.var != VAR_GLOBAL) {
         C.gtiles = nullptr;
@@ -311,10 +363,16 @@ int run_pack(const Plan& plan, hipStream_t st) {
 
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, hipStream_t st) {
     if (io.rows <= 0) return CSMPN_OK;
-    const long ntiles = (io.rows + 15) / 16;
+    const long R = 16 * plan.H;
+    const long ntiles = (io.rows + R - 1) / R;
     long grid = (ntiles + plan.C.RT - 1) / plan.C.RT;
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
-    HIP_TRY(launch_cemlp(id, mode, plan.var, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
+    static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
+    if (debug)
+        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
+                mode, (int)bwd, plan.var, plan.H, plan.C.MT, plan.C.RT, plan.threads, plan.lds_bytes, grid,
+                plan.C.tile_floats, plan.C.mirror_floats, io.rows);
+    HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
     return CSMPN_OK;
 }
 
@@ -447,19 +505,28 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
 
 size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks) {
     if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
-    size_t bytes = packed_f4_count(n + 1, blocks, n_blocks) * sizeof(f4);
+    // H is not known without the metric: reserve for the larger packing (H = 2 when narrow)
     int maxO = 0;
     for (int k = 0; k < n_blocks; ++k) maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
-    const int D = 1 << n, MT = cdiv(maxO, 16);
-    // worst case over the entry points: backward layout with the edge-forward staging row
-    const TileLayout L = tile_layout(D, blocks, n_blocks, true, blocks[n_blocks - 1].out_features * D);
-    const Choice ch = choose_variant(MT, (size_t)L.total * 4, 0, true);
-    const Choice chf = choose_variant(MT, (size_t)L.total * 4, 0, false);
-    if (ch.var == VAR_GLOBAL || chf.var == VAR_GLOBAL) {
-        const int rt = ch.rt > chf.rt ? ch.rt : chf.rt;
-        bytes += (size_t)kGlobalTileGrid * rt * L.total * 4;
+    size_t bytes = packed_f4_count(n + 1, 1, blocks, n_blocks) * sizeof(f4);
+    if (maxO <= 8) {
+        const size_t b2 = packed_f4_count(n + 1, 2, blocks, n_blocks) * sizeof(f4);
+        bytes = b2 > bytes ? b2 : bytes;
     }
-    return bytes;
+    const int D = 1 << n, MT = cdiv(maxO, 16);
+    // worst case over the entry points (H = 1): backward layout / forward layout with the
+    // edge-forward staging row
+    const TileLayout Lb = tile_layout(D, 1, blocks, n_blocks, true, 0);
+    const TileLayout Lf = tile_layout(D, 1, blocks, n_blocks, false, blocks[n_blocks - 1].out_features * D);
+    const Choice cb = choose_variant(MT, (size_t)Lb.total * 4, 0, true);
+    const Choice cf = choose_variant(MT, (size_t)Lf.total * 4, 0, false);
+    size_t scratch = 0;
+    if (cb.var == VAR_GLOBAL) scratch = (size_t)kGlobalTileGrid * cb.rt * Lb.total * 4;
+    if (cf.var == VAR_GLOBAL) {
+        const size_t s2 = (size_t)kGlobalTileGrid * cf.rt * Lf.total * 4;
+        scratch = s2 > scratch ? s2 : scratch;
+    }
+    return bytes + scratch;
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,

@@ -1,21 +1,29 @@
 // Fused CEMLP block (MVLinear -> MVSiLU -> SteerableGeometricProduct(+Normalization)
-// -> MVLayerNorm) forward and recompute-backward for gfx950, one 16-row tile at a time.
+// -> MVLayerNorm) forward and recompute-backward for gfx950, one row tile at a time.
 //
 // Follows the arithmetic of csmpn/models/cegnn_utils.py:34-155,287-338 (SURVEY.md
 // Appendix A), re-derived for the hardware:
 //
-//  * Lane layout of every activation tensor ("lane layout"): a wave owns a tile of
-//    16 rows x 16 channels. lane l: channel c = 16*mt + (l & 15), rows 4*(l >> 4) + v,
-//    v = 0..3, all D blades in registers:  f4 t[D]  (t[d][v]).  This is exactly the
-//    C/D layout of v_mfma_f32_16x16x4_f32 with M = rows, N = channels.
-//  * Dense channel mixing (MVLinear, linear_left/right and their transposes) runs on
-//    the fp32 MFMA: A = activations read from an LDS tile [row][blade][channel]
-//    (one ds_read_b128 = 4 k-steps), B = weights pre-packed in fragment order.
+//  * Lane layout of every activation tensor: a wave owns a tile of R = 16*H rows and 16
+//    lane columns. lane l: column n = l & 15, quarter q = l >> 4.
+//      H = 1: channel c = 16*mt + n,          rows 4q + v           (16 rows x 16 channels)
+//      H = 2: half h = n >> 3, c = n & 7,     rows 16h + 4q + v     (32 rows x 8 channels)
+//    v = 0..3 are the four accumulator registers of v_mfma_f32_16x16x4_f32, all D blades
+//    of a (row, channel) pair sit in one lane:  f4 t[D]  (t[d][v]).
+//    H = 2 exists for channel counts <= 8: with H = 1 half of the lane columns would carry
+//    padding channels through all the VALU work.
+//  * Dense channel mixing (MVLinear, linear_left/right and their transposes) runs on the
+//    fp32 MFMA: A = activations from an LDS tile, B = weights pre-packed in fragment order
+//    (for H = 2 one fragment per row half, zero in the other half's columns).
+//  * LDS tile layout [channel][blade][row]: every stride is a compile-time constant of the
+//    algebra (independent of the channel counts), so ds_* instructions use immediate
+//    offsets; a lane stores its 4 rows with one ds_write_b128 and weight-gradient B operands
+//    are read with one ds_read_b128 per 4 k-steps.
 //  * Weight gradients are MFMAs whose A operand is the lane-layout gradient itself
 //    (registers) and whose B operand is the input-side tile in LDS.
-//  * Everything else (gates, norms, the sign-table geometric product with D^2
-//    products per channel instead of the reference's dense D^3 einsum) is VALU work
-//    in registers, fully unrolled with compile-time signs and indices.
+//  * Everything else (gates, norms, the sign-table geometric product with D^2 products per
+//    channel instead of the reference's dense D^3 einsum) is VALU work in registers, fully
+//    unrolled with compile-time signs and indices.
 //  * Backward stores no [rows, C, D] activations: it recomputes the block forward.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,8 +35,7 @@ namespace csmpn {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define CSMPN_DEV __device__ __forceinline__
-// stop the instruction scheduler from moving code across a phase boundary (keeps the live
-// register set of one phase from overlapping the next one's)
+// stop the instruction scheduler from moving code across a phase boundary
 #define CSMPN_PHASE() __builtin_amdgcn_sched_barrier(0)
 
 constexpr float kInvSqrt2 = 0.70710678118654752440f;
@@ -40,27 +47,28 @@ constexpr float kSmooth = 1e-16f;    // cliffordalgebra.py:148
 
 struct DevBlock {
     int I, O;            // in / out channels
-    int KKi, KKo;        // ceil(I/16), ceil(O/16)
-    int CPi, CPo;        // channels padded to a multiple of 4 (LDS tile width)
+    int KKi, KKo;        // ceil(I/16), ceil(O/16): k-blocks of 16 channels
+    int NTi, NTo;        // ceil(I/NW), ceil(O/NW): N tiles of NW = 16/H channels
+    int CPi, CPo;        // channels padded to a multiple of 4
     int has_b1;          // MVLinear bias present
     int lds_goff;        // float offset of this block's gradient mirror in LDS
+    int w1_sub;          // 1: W1 is [O,I,G]; 0: [O,I]
+    int pad_;
     // small parameters, reference layouts
     const float *b1, *sa, *sb, *w, *an, *bL, *la;
-    // packed weight fragments (f4 per lane): forward [g][nt][kk][64], transposed [g][it][kk][64]
+    // packed weight fragments (f4 per lane): forward [nt][kk][hp][g][64], transposed [it][kk][hp][g][64]
     const f4 *pfW1, *pfWR, *pfWL, *pbW1, *pbWR, *pbWL;
     // gradient accumulators, reference layouts (global)
     float *gW1, *gb1, *gsa, *gsb, *gw, *gan, *gWR, *gWL, *gbL, *gla;
-    int w1_sub;          // 1: W1 is [O,I,G]; 0: [O,I]
-    int pad_;
 };
 
 struct DevCemlp {
     int nblk;
-    int MT;              // waves cooperating on one row tile = ceil(max O / 16)
+    int MT;              // waves cooperating on one row tile = ceil(max O / NW)
     int RT;              // row tiles per workgroup
-    int grads_in_lds;    // gradient mirror lives in LDS (flushed once per workgroup)
-    int off_in, off_p0, off_p1, off_z, off_g, off_red;  // float offsets inside one row tile's LDS region
-    int tile_floats;     // LDS floats per row tile
+    int H;               // row halves per tile (1 or 2)
+    int off_in, off_p0, off_p1, off_z, off_g, off_red;  // float offsets inside one row tile's buffers
+    int tile_floats;     // floats per row tile
     int mirror_floats;   // LDS floats of the gradient mirror (0 if not used)
     float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
     DevBlock b[4];
@@ -98,6 +106,33 @@ struct RowIO {
     int pad2_;
 };
 
+// Storage variants of the row-tile buffers (compile time, so that the LDS variants use
+// pure LDS addressing: ds_* instructions instead of flat_*):
+//   VAR_WAVE      one wave owns a row tile; buffers + gradient mirror in LDS; no barriers
+//   VAR_GROUP     MT waves share a row tile; buffers + mirror in LDS; workgroup barriers
+//   VAR_GROUP_NM  as VAR_GROUP, but the gradient mirror does not fit beside the tiles:
+//                 parameter gradients go to the global accumulators directly
+//   VAR_GLOBAL    buffers in a global scratch (tiles beyond 160 KB of LDS), gradients by
+//                 global atomics, workgroup barriers
+enum { VAR_WAVE = 0, VAR_GROUP = 1, VAR_GROUP_NM = 2, VAR_GLOBAL = 3 };
+template <int VAR> constexpr bool kVarBarrier = VAR != VAR_WAVE;
+template <int VAR> constexpr bool kVarMirror = VAR == VAR_WAVE || VAR == VAR_GROUP;
+
+// geometry of a row tile
+template <class ALG, int H>
+struct Geo {
+    static constexpr int D = ALG::D, G = ALG::G;
+    static constexpr int R = 16 * H;        // rows per tile
+    static constexpr int NW = 16 / H;       // channels per N tile (lane columns per half)
+    static constexpr int CS = R * D + 4;    // LDS channel stride (floats); +4 breaks the bank pattern
+    int lane, n, q, h, cn, r0;
+    CSMPN_DEV explicit Geo(int lane_) : lane(lane_), n(lane_ & 15), q(lane_ >> 4) {
+        h = H == 1 ? 0 : (n >> 3);
+        cn = H == 1 ? n : (n & 7);
+        r0 = 16 * h + 4 * q;                // first of the lane's 4 rows
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // small helpers
 
@@ -109,26 +144,25 @@ template <int CTRL>
 CSMPN_DEV float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
-// sum over the 16 lanes of a DPP row (= the 16 channels of a wave tile); result in every lane
-CSMPN_DEV float row16_sum(float v) {
+// sum over the NW lane columns that hold the channels of one row; result in every lane
+template <int H>
+CSMPN_DEV float chan_sum(float v) {
     v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_mov<0x124>(v);  // row_ror 4
-    v += dpp_mov<0x128>(v);  // row_ror 8
+    if constexpr (H == 1) {
+        v += dpp_mov<0x124>(v);  // row_ror 4
+        v += dpp_mov<0x128>(v);  // row_ror 8
+    } else {
+        v += dpp_mov<0x141>(v);  // row_half_mirror: the other quad of the same 8 lanes
+    }
     return v;
 }
-CSMPN_DEV f4 row16_sum4(f4 v) {
-    f4 o;
-    o.x = row16_sum(v.x); o.y = row16_sum(v.y); o.z = row16_sum(v.z); o.w = row16_sum(v.w);
-    return o;
+template <int H>
+CSMPN_DEV f4 chan_sum4(f4 v) {
+    return f4{chan_sum<H>(v.x), chan_sum<H>(v.y), chan_sum<H>(v.z), chan_sum<H>(v.w)};
 }
 CSMPN_DEV float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
-// sum over the 4 row-quarters (lanes l, l^16, l^32, l^48)
-CSMPN_DEV float quarters_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
+
 // Accuracy: the parity bar is 1e-5 relative against the reference's fp32 CPU path. The
 // hardware approximations (v_rcp_f32, v_exp_f32, v_rsq_f32: ~1 ulp) are each refined by one
 // Newton / compensation step (2-4 FMAs), which brings them to <=1 ulp of the exact value at
@@ -166,18 +200,6 @@ CSMPN_DEV f4 sqrt4(f4 x) { return f4{sqrt_pos(x.x), sqrt_pos(x.y), sqrt_pos(x.z)
 CSMPN_DEV f4 smooth_abs_sqrt4(f4 q) { return sqrt4(sqrt4(q * q + kSmooth)); }
 CSMPN_DEV f4 splat(float v) { return f4{v, v, v, v}; }
 
-// Storage variants of the row-tile buffers (compile time, so that the LDS variants use
-// pure LDS addressing: ds_* instructions instead of flat_*):
-//   VAR_WAVE      one wave owns a row tile; buffers + gradient mirror in LDS; no barriers
-//   VAR_GROUP     MT waves share a row tile; buffers + mirror in LDS; workgroup barriers
-//   VAR_GROUP_NM  as VAR_GROUP, but the gradient mirror does not fit beside the tiles:
-//                 parameter gradients go to the global accumulators directly
-//   VAR_GLOBAL    buffers in a global scratch (tiles beyond 160 KB of LDS), gradients by
-//                 global atomics, workgroup barriers
-enum { VAR_WAVE = 0, VAR_GROUP = 1, VAR_GROUP_NM = 2, VAR_GLOBAL = 3 };
-template <int VAR> constexpr bool kVarBarrier = VAR != VAR_WAVE;
-template <int VAR> constexpr bool kVarMirror = VAR == VAR_WAVE || VAR == VAR_GROUP;
-
 template <int VAR>
 CSMPN_DEV void tile_sync() {
     if constexpr (kVarBarrier<VAR>) {
@@ -194,66 +216,74 @@ CSMPN_DEV void tile_sync() {
 // ---------------------------------------------------------------------------------
 // MFMA pieces
 
-// acc[d][v] += sum_in  T[row][d][in] * W[c][in][grade(d)]
-// tile: LDS [16][D][CP] with row stride RS; frags: [g][kk][64] f4 for this wave's channel tile
-template <class ALG>
-CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int RS, int CP, int KK,
-                                const f4* frags, int lane) {
-    constexpr int D = ALG::D, G = ALG::G;
-    const int row = lane & 15, kq = lane >> 4;
+// acc[d][v] += sum_in  T[in][d][row] * W[c][in][grade(d)]
+// tile: [channel][D][R] (channel stride CS); CP = valid channels (multiple of 4);
+// frags: [kk][hp][g][64] f4 for this wave's N tile
+template <class ALG, int H>
+CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, int KK, const f4* frags,
+                                const Geo<ALG, H>& ge) {
+    using GE = Geo<ALG, H>;
+    constexpr int G = ALG::G, R = GE::R, CS = GE::CS;
     for (int kk = 0; kk < KK; ++kk) {
-        const int c0 = 16 * kk + 4 * kq;
+        const int c0 = 16 * kk + 4 * ge.q;
         const bool valid = c0 < CP;
-        const float* ap = tile + row * RS + c0;
-        static_for<0, G>([&](auto g) {
-            const f4 b = frags[(g * KK + kk) * 64 + lane];
-            constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-            f4 a[nd];
+        const float* ap = tile + c0 * CS + ge.n;
+        const f4* fp = frags + (size_t)kk * (H * G * 64) + ge.lane;
 #pragma unroll
-            for (int t = 0; t < nd; ++t)
-                a[t] = valid ? *reinterpret_cast<const f4*>(ap + (d0 + t) * CP) : splat(0.f);
+        for (int hp = 0; hp < H; ++hp) {
+            static_for<0, G>([&](auto g) {
+                const f4 b = fp[(hp * G + g) * 64];
+                constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+                for (int v = 0; v < 4; ++v) {
 #pragma unroll
-                for (int t = 0; t < nd; ++t) acc[d0 + t] = mfma16(a[t][v], b[v], acc[d0 + t]);
-        });
+                    for (int t = 0; t < nd; ++t) {
+                        const float a = valid ? ap[v * CS + (d0 + t) * R + 16 * hp] : 0.f;
+                        acc[d0 + t] = mfma16(a, b[v], acc[d0 + t]);
+                    }
+                }
+            });
+        }
     }
 }
 
-// Weight gradient tiles for one linear: for every input-channel tile it and grade g
-//   gW[o = 16*mt + 4*(l>>4) + v][c = 16*it + (l&15)][g] += sum_{rows, d in g} Gr[row][d][o] * T[row][d][c]
-// A operand = lane-layout gradient (registers), B operand = input-side LDS tile.
-// Accumulates into `dstp` (LDS mirror laid out [g][O][I], or global reference layout).
-template <class ALG, bool dst_is_mirror>
-CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int RS, int CP, int I, int O, int KKin,
-                           int mt, int lane, float* dstp, bool has_grades) {
-    constexpr int D = ALG::D, G = ALG::G;
-    const int n = lane & 15, q = lane >> 4;
-    for (int it = 0; it < KKin; ++it) {
-        const int c = 16 * it + n;
-        const bool cvalid = c < CP;
+// Weight gradient tiles of one linear: for every input-channel tile it and grade g
+//   gW[o][cin][g] += sum_{rows, d in g} Gr[row][d][o] * T[cin][d][row]
+// A operand = lane-layout gradient (registers), B operand = input-side LDS tile (one
+// ds_read_b128 = the lane's 4 rows = 4 k-steps). MIRROR: dst is the LDS mirror laid out
+// [g][O][I]; otherwise the global reference layout [O][I][G] (or [O][I]).
+template <class ALG, int H, bool MIRROR>
+CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int CP, int I, int O, int NTin, int mt,
+                           const Geo<ALG, H>& ge, float* dstp, bool has_grades) {
+    using GE = Geo<ALG, H>;
+    constexpr int G = ALG::G, R = GE::R, CS = GE::CS, NW = GE::NW;
+    // output element (i = 4q + v', j = n) of the MFMA: i -> (row half, out channel)
+    const int hi = H == 1 ? 0 : (ge.q >> 1);
+    const int ob = NW * mt + (H == 1 ? 4 * ge.q : 4 * (ge.q & 1));
+    for (int it = 0; it < NTin; ++it) {
+        const int cin = NW * it + ge.cn;
+        const bool cvalid = cin < CP;
+        const float* bp = tile + cin * CS + ge.r0;
         f4 accg[G];
         static_for<0, G>([&](auto g) {
             f4 acc = splat(0.f);
             constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
 #pragma unroll
             for (int t = 0; t < nd; ++t) {
+                const f4 b = cvalid ? *reinterpret_cast<const f4*>(bp + (d0 + t) * R) : splat(0.f);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float b = cvalid ? tile[(4 * q + v) * RS + (d0 + t) * CP + c] : 0.f;
-                    acc = mfma16(gr[d0 + t][v], b, acc);
-                }
+                for (int v = 0; v < 4; ++v) acc = mfma16(gr[d0 + t][v], b[v], acc);
             }
             accg[g] = acc;
         });
-        if (c < I) {
+        if (cin < I && hi == ge.h) {
             if (has_grades) {
                 static_for<0, G>([&](auto g) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int o = 16 * mt + 4 * q + v;
+                        const int o = ob + v;
                         if (o < O) {
-                            float* p = dst_is_mirror ? dstp + (g * O + o) * I + c : dstp + (o * I + c) * G + g;
+                            float* p = MIRROR ? dstp + (g * O + o) * I + cin : dstp + (o * I + cin) * G + g;
                             atomicAdd(p, accg[g][v]);
                         }
                     }
@@ -263,24 +293,24 @@ CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int RS, in
                 static_for<1, G>([&](auto g) { tot += accg[g]; });
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int o = 16 * mt + 4 * q + v;
-                    if (o < O) atomicAdd(dstp + o * I + c, tot[v]);
+                    const int o = ob + v;
+                    if (o < O) atomicAdd(dstp + o * I + cin, tot[v]);
                 }
             }
         }
     }
 }
 
-// write a lane-layout tensor into an LDS tile [row][d][CP]
-template <class ALG>
-CSMPN_DEV void store_tile(const f4 (&t)[ALG::D], float* tile, int RS, int CP, int mt, int lane) {
-    constexpr int D = ALG::D;
-    const int c = 16 * mt + (lane & 15), q = lane >> 4;
+// write a lane-layout tensor into an LDS tile [channel][D][R]: one b128 per blade
+template <class ALG, int H>
+CSMPN_DEV void store_tile(const f4 (&t)[ALG::D], float* tile, int CP, int mt, const Geo<ALG, H>& ge) {
+    using GE = Geo<ALG, H>;
+    constexpr int D = ALG::D, R = GE::R, CS = GE::CS, NW = GE::NW;
+    const int c = NW * mt + ge.cn;
     if (c < CP) {
+        float* p = tile + c * CS + ge.r0;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) tile[(4 * q + v) * RS + d * CP + c] = t[d][v];
+        for (int d = 0; d < D; ++d) *reinterpret_cast<f4*>(p + d * R) = t[d];
     }
 }
 
@@ -351,13 +381,13 @@ CSMPN_DEV void weighted_gp(f4 (&out)[ALG::D], const f4 (&z)[ALG::D], const f4 (&
     });
 }
 
-// backward of weighted_gp: gz, gr accumulate; gw[p] is reduced over the tile's rows and
-// added to gw_dst. The left/right operands z = gate*y and r = R*invden are rebuilt per path
-// from the kept forward state instead of being held in registers (64 VGPRs less).
+// backward of weighted_gp: gz, gr accumulate; gw[p] (summed over the lane's 4 rows) is
+// returned per lane. The operands z = gate*y and r = R*invden are rebuilt per path from
+// the kept forward state instead of being held in registers.
 template <class ALG>
 CSMPN_DEV void weighted_gp_bwd(const f4 (&ggp)[ALG::D], const f4 (&y)[ALG::D], const f4 (&gate)[ALG::G],
                                const f4 (&R)[ALG::D], const f4 (&invden)[ALG::G], const float* wrow,
-                               f4 (&gz)[ALG::D], f4 (&gr)[ALG::D], float* gw_dst, bool lane0q, bool cvalid) {
+                               f4 (&gz)[ALG::D], f4 (&gr)[ALG::D], float (&gw)[ALG::P]) {
     constexpr int P = ALG::P;
     static_for<0, P>([&](auto p) {
         constexpr int gi = ALG::t.path_g[p][0], gj = ALG::t.path_g[p][1], gk = ALG::t.path_g[p][2];
@@ -386,8 +416,7 @@ CSMPN_DEV void weighted_gp_bwd(const f4 (&ggp)[ALG::D], const f4 (&y)[ALG::D], c
         f4 gwv = splat(0.f);
 #pragma unroll
         for (int t = 0; t < ni; ++t) { gz[i0 + t] += w * U[t]; gwv += zi[t] * U[t]; }
-        const float tot = quarters_sum(hsum(gwv));
-        if (lane0q && cvalid) atomicAdd(gw_dst + p, tot);
+        gw[p] = hsum(gwv);
     });
 }
 
@@ -413,19 +442,22 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 // ---------------------------------------------------------------------------------
 // block forward. Input tile in LDS (xin), output in lane layout (out) for this wave's
 // channel tile. zbuf: LDS tile for the gated activations (feeds linear_left/right).
-// red: LDS scratch [MT][16] floats for cross-wave LayerNorm sums (MULTI only).
-template <class ALG, int VAR>
+// red: scratch [MT][16] floats for cross-wave LayerNorm sums (barrier variants only).
+template <class ALG, int H, int VAR>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
-                             float* red, int MT, int mt, int lane, FwdState<ALG>& S, f4 (&out)[ALG::D]) {
-    constexpr int D = ALG::D, G = ALG::G;
-    const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
-    const int c = 16 * mt + (lane & 15), q = lane >> 4;
-    const bool tile_active = 16 * mt < B.O;
+                             float* red, int MT, int mt, const Geo<ALG, H>& ge, FwdState<ALG>& S,
+                             f4 (&out)[ALG::D]) {
+    using GE = Geo<ALG, H>;
+    static_assert(H == 1 || !kVarBarrier<VAR>, "multi-wave row tiles use H = 1");
+    constexpr int D = ALG::D, G = ALG::G, NW = GE::NW;
+    const int c = NW * mt + ge.cn;
+    const bool tile_active = NW * mt < B.O;
+    const size_t fstride = (size_t)H * G * 64;   // f4 per (N tile, k-block)
 
     // 1. MVLinear (cegnn_utils.py:326-338)
 #pragma unroll
     for (int d = 0; d < D; ++d) S.y[d] = splat(0.f);
-    if (tile_active) linear_from_tile<ALG>(S.y, xin, RSi, B.CPi, B.KKi, B.pfW1 + (size_t)mt * G * B.KKi * 64, lane);
+    if (tile_active) linear_from_tile<ALG, H>(S.y, xin, B.CPi, B.KKi, B.pfW1 + mt * fstride * B.KKi, ge);
     S.y[0] += lp.b1;
 
     CSMPN_PHASE();
@@ -447,7 +479,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 #pragma unroll
         for (int t = 0; t < nd; ++t) z[d0 + t] = S.gate[g] * S.y[d0 + t];
     });
-    store_tile<ALG>(z, zbuf, RSo, B.CPo, mt, lane);
+    store_tile<ALG, H>(z, zbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
 
     CSMPN_PHASE();
@@ -456,8 +488,8 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 #pragma unroll
     for (int d = 0; d < D; ++d) { S.R[d] = splat(0.f); L[d] = splat(0.f); }
     if (tile_active) {
-        linear_from_tile<ALG>(S.R, zbuf, RSo, B.CPo, B.KKo, B.pfWR + (size_t)mt * G * B.KKo * 64, lane);
-        linear_from_tile<ALG>(L, zbuf, RSo, B.CPo, B.KKo, B.pfWL + (size_t)mt * G * B.KKo * 64, lane);
+        linear_from_tile<ALG, H>(S.R, zbuf, B.CPo, B.KKo, B.pfWR + mt * fstride * B.KKo, ge);
+        linear_from_tile<ALG, H>(L, zbuf, B.CPo, B.KKo, B.pfWL + mt * fstride * B.KKo, ge);
     }
     L[0] += lp.bL;
 
@@ -492,12 +524,12 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     });
     S.qs = qs;
     S.nl = smooth_abs_sqrt4(qs);
-    f4 tot = row16_sum4(lp.cvalid ? S.nl : splat(0.f));
+    f4 tot = chan_sum4<H>(lp.cvalid ? S.nl : splat(0.f));
     if constexpr (kVarBarrier<VAR>) {
-        if ((lane & 15) == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * q) = tot;
+        if (ge.n == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * ge.q) = tot;
         __syncthreads();
         tot = splat(0.f);
-        for (int m = 0; m < MT; ++m) tot += *reinterpret_cast<const f4*>(red + m * 16 + 4 * q);
+        for (int m = 0; m < MT; ++m) tot += *reinterpret_cast<const f4*>(red + m * 16 + 4 * ge.q);
         __syncthreads();
     }
     S.invMn = rcp4(tot * (1.0f / float(B.O)) + kEps);
@@ -509,20 +541,22 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 // block backward: given the forward state S of this tile and gout (lane layout),
 // accumulate all parameter gradients and leave d/d(MVLinear output) in gy (lane
 // layout) AND in the LDS tile gbuf (so the caller can run the transposed MVLinear).
-template <class ALG, int VAR>
+template <class ALG, int H, int VAR>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
-                              float* red, float* mirror, int MT, int mt, int lane, f4 (&gy)[ALG::D]) {
-    constexpr int D = ALG::D, G = ALG::G, P = ALG::P;
-    const int RSi = D * B.CPi + 4, RSo = D * B.CPo + 4;
-    const int c = 16 * mt + (lane & 15), q = lane >> 4;
-    const bool tile_active = 16 * mt < B.O;
-    const bool lane0q = q == 0;
+                              float* red, float* mirror, int MT, int mt, const Geo<ALG, H>& ge,
+                              f4 (&gy)[ALG::D]) {
+    using GE = Geo<ALG, H>;
+    constexpr int D = ALG::D, G = ALG::G, P = ALG::P, NW = GE::NW;
+    const int c = NW * mt + ge.cn;
+    const bool tile_active = NW * mt < B.O;
     const bool cv = lp.cvalid;
+    const int cc = cv ? c : 0;
+    const size_t fstride = (size_t)H * G * 64;
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, P, B.w1_sub != 0);
     float* mir = mirror + B.lds_goff;
-    // gradient destinations: LDS mirror (flushed once per workgroup) or, in the global-tile
-    // variant, the global reference-layout accumulators directly
+    // gradient destinations: LDS mirror (flushed once per workgroup) or, in the variants
+    // without mirror, the global reference-layout accumulators directly
     constexpr bool in_lds = kVarMirror<VAR>;
     float *d_b1, *d_sa, *d_sb, *d_w, *d_an, *d_bL, *d_la, *d_W1, *d_WR, *d_WL;
     if constexpr (in_lds) {
@@ -532,22 +566,21 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         d_b1 = B.gb1; d_sa = B.gsa; d_sb = B.gsb; d_w = B.gw; d_an = B.gan;
         d_bL = B.gbL; d_la = B.gla; d_W1 = B.gW1; d_WR = B.gWR; d_WL = B.gWL;
     }
+    // per-lane partial sums (over the lane's 4 rows) of the small-parameter gradients; all
+    // lanes of a channel add them to the accumulators in one predicated region at the end
+    float p_la, p_bL, p_b1, p_an[G], p_sa[G], p_sb[G], p_w[P];
 
     // ---- MVLayerNorm backward
-    f4 dot = splat(0.f), gla = splat(0.f);
+    f4 dot = splat(0.f);
 #pragma unroll
-    for (int d = 0; d < D; ++d) { dot += gout[d] * S.s[d]; }
-    gla = dot * S.invMn;
-    {
-        const float t = quarters_sum(hsum(gla));
-        if (lane0q && cv) atomicAdd(d_la + c, t);
-    }
-    f4 gMn = row16_sum4(-(lp.la * dot) * S.invMn * S.invMn);
+    for (int d = 0; d < D; ++d) dot += gout[d] * S.s[d];
+    p_la = hsum(dot * S.invMn);
+    f4 gMn = chan_sum4<H>(-(lp.la * dot) * S.invMn * S.invMn);
     if constexpr (kVarBarrier<VAR>) {
-        if ((lane & 15) == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * q) = gMn;
+        if (ge.n == 0) *reinterpret_cast<f4*>(red + mt * 16 + 4 * ge.q) = gMn;
         __syncthreads();
         gMn = splat(0.f);
-        for (int m = 0; m < MT; ++m) gMn += *reinterpret_cast<const f4*>(red + m * 16 + 4 * q);
+        for (int m = 0; m < MT; ++m) gMn += *reinterpret_cast<const f4*>(red + m * 16 + 4 * ge.q);
         __syncthreads();
     }
     // d nl/d qs = 0.5 * qs / nl^3
@@ -559,21 +592,18 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         const f4 gs = (lp.la * gout[d]) * S.invMn + gqs * (2.0f * qsf<ALG, d>) * S.s[d];
         ggp[d] = cv ? gs * kInvSqrt2 : splat(0.f);
     });
-    {
-        const float t = quarters_sum(hsum(ggp[0]));
-        if (lane0q && cv) atomicAdd(d_bL + c, t);
-    }
+    p_bL = hsum(ggp[0]);
 
     CSMPN_PHASE();
     // ---- d/dz from linear_left: gz = GL . WL^T ; gWL += GL (x) Z
-    store_tile<ALG>(ggp, gbuf, RSo, B.CPo, mt, lane);
+    store_tile<ALG, H>(ggp, gbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
     f4 gz[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gz[d] = splat(0.f);
     if (tile_active) {
-        linear_from_tile<ALG>(gz, gbuf, RSo, B.CPo, B.KKo, B.pbWL + (size_t)mt * G * B.KKo * 64, lane);
-        weight_grad<ALG, in_lds>(ggp, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WL, true);
+        linear_from_tile<ALG, H>(gz, gbuf, B.CPo, B.KKo, B.pbWL + mt * fstride * B.KKo, ge);
+        weight_grad<ALG, H, in_lds>(ggp, zbuf, B.CPo, B.O, B.O, B.NTo, mt, ge, d_WL, true);
     }
 
     CSMPN_PHASE();
@@ -581,9 +611,9 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     f4 gr[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gr[d] = splat(0.f);
-    if (tile_active)
-        weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, B.w + (size_t)(cv ? c : 0) * P, gz, gr,
-                             d_w + (size_t)(cv ? c : 0) * P, lane0q, cv);
+#pragma unroll
+    for (int p = 0; p < P; ++p) p_w[p] = 0.f;
+    if (tile_active) weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, B.w + (size_t)cc * P, gz, gr, p_w);
 
     CSMPN_PHASE();
     // ---- NormalizationLayer backward -> gR (q_g and nu_g are rebuilt from R)
@@ -598,10 +628,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         });
         gden *= S.invden[g] * S.invden[g];      // d/d(den): -sum gr * R / den^2
         const f4 nu = smooth_abs_sqrt4(qR);
-        {
-            const float t = quarters_sum(hsum(gden * (nu - 1.0f))) * lp.sg[g] * (1.0f - lp.sg[g]);
-            if (lane0q && cv) atomicAdd(d_an + c * G + g, t);
-        }
+        p_an[g] = hsum(gden * (nu - 1.0f)) * lp.sg[g] * (1.0f - lp.sg[g]);
         const f4 inu = rcp4(nu);
         const f4 gq = (gden * lp.sg[g]) * (0.5f * qR) * (inu * inu * inu);
         static_for<0, nd>([&](auto t) {
@@ -610,11 +637,11 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         });
     });
     tile_sync<VAR>();   // all reads of gbuf (GL) done
-    store_tile<ALG>(gR, gbuf, RSo, B.CPo, mt, lane);
+    store_tile<ALG, H>(gR, gbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
     if (tile_active) {
-        linear_from_tile<ALG>(gz, gbuf, RSo, B.CPo, B.KKo, B.pbWR + (size_t)mt * G * B.KKo * 64, lane);
-        weight_grad<ALG, in_lds>(gR, zbuf, RSo, B.CPo, B.O, B.O, B.KKo, mt, lane, d_WR, true);
+        linear_from_tile<ALG, H>(gz, gbuf, B.CPo, B.KKo, B.pbWR + mt * fstride * B.KKo, ge);
+        weight_grad<ALG, H, in_lds>(gR, zbuf, B.CPo, B.O, B.O, B.NTo, mt, ge, d_WR, true);
     }
 
     CSMPN_PHASE();
@@ -635,11 +662,8 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
                 u += qsf<ALG, d> * S.y[d] * S.y[d];
             });
         }
-        {
-            const float ta = quarters_sum(hsum(gpre * u));
-            const float tb = quarters_sum(hsum(gpre));
-            if (lane0q && cv) { atomicAdd(d_sa + c * G + g, ta); atomicAdd(d_sb + c * G + g, tb); }
-        }
+        p_sa[g] = hsum(gpre * u);
+        p_sb[g] = hsum(gpre);
         const f4 gu = gpre * lp.sa[g];
         static_for<0, nd>([&](auto t) {
             constexpr int d = d0 + decltype(t)::value;
@@ -649,15 +673,32 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
             gy[d] = cv ? v : splat(0.f);
         });
     });
-    if (B.has_b1) {
-        const float t = quarters_sum(hsum(gy[0]));
-        if (lane0q && cv) atomicAdd(d_b1 + c, t);
-    }
+    p_b1 = hsum(gy[0]);
+
     CSMPN_PHASE();
+    // ---- small-parameter gradients: one predicated region, every lane of the channel adds
+    // its 4-row partial (the 4*H lanes of a channel hit one address; the LDS atomic unit
+    // serialises them, which is cheaper than cross-lane reductions plus per-value branches)
+    if (cv) {
+        atomicAdd(d_la + c, p_la);
+        atomicAdd(d_bL + c, p_bL);
+        if (B.has_b1) atomicAdd(d_b1 + c, p_b1);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            atomicAdd(d_an + c * G + g, p_an[g]);
+            atomicAdd(d_sa + c * G + g, p_sa[g]);
+            atomicAdd(d_sb + c * G + g, p_sb[g]);
+        }
+        if (tile_active) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) atomicAdd(d_w + (size_t)c * P + p, p_w[p]);
+        }
+    }
+
     // ---- MVLinear weight gradient; gy tile to LDS for the transposed MVLinear
     tile_sync<VAR>();   // all reads of gbuf (GR) done
-    store_tile<ALG>(gy, gbuf, RSo, B.CPo, mt, lane);
-    if (tile_active) weight_grad<ALG, in_lds>(gy, xin, RSi, B.CPi, B.I, B.O, B.KKi, mt, lane, d_W1, B.w1_sub != 0);
+    store_tile<ALG, H>(gy, gbuf, B.CPo, mt, ge);
+    if (tile_active) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
     tile_sync<VAR>();
 }
 

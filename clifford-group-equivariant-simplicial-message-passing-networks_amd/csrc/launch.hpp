@@ -8,7 +8,8 @@ namespace csmpn {
 constexpr int kMaxLdsBytes = 160 * 1024;
 
 #define CSMPN_DECLARE_ALG(tag)                                                                                  \
-    hipError_t launch_cemlp_##tag(int mode, int var, bool bwd, unsigned grid, unsigned block, size_t lds,   \
+    bool has_h2_##tag();                                                                                        \
+    hipError_t launch_cemlp_##tag(int mode, int var, int h, bool bwd, unsigned grid, unsigned block, size_t lds,   \
                                   hipStream_t st, const DevCemlp& C, const RowIO& io);                          \
     hipError_t launch_gp_##tag(bool bwd, const float* a, const float* b, const float* gout, float* out,        \
                                float* ga, float* gb, long rows, hipStream_t st);
