@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsmpn_hip.so")
+LIB_PATH = os.environ.get("CSMPN_LIB") or os.path.join(_HERE, "libcsmpn_hip.so")
 
 MAX_BLOCKS = 4
 FLAG_WEIGHTS_PACKED = 1

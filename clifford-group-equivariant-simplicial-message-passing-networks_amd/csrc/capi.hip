@@ -151,7 +151,7 @@ struct Plan {
 };
 
 // floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
-struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, total; };
+struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, off_idx, total; };
 TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen) {
     int maxO = 0, maxCPo = 0;
     for (int k = 0; k < nblk; ++k) {
@@ -174,19 +174,20 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
     if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
     off += sz_g;
     L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
+    L.off_idx = off; off += rup(3 * R, 4);   // int copies of the tile's gathered row indices
     L.total = off;
     return L;
 }
 struct Choice { int var, rt, wgs; bool mirror; };
 // backward kernels are built for 256 threads (512 VGPRs), forward for 512 threads
-Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, bool bwd) {
+Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wstore_bytes, bool bwd) {
     const int max_rt = ((bwd ? 4 : 8) / MT) > 0 ? (bwd ? 4 : 8) / MT : 1;
-    auto fit = [&](size_t mbytes, int& rt_out, int& wgs_out) {
+    auto fit = [&](size_t fixed, int& rt_out, int& wgs_out) {
         int best_waves = 0;
         for (int wgs = 1; wgs <= 2; ++wgs) {
             const size_t budget = (size_t)kMaxLdsBytes / wgs;
-            if (budget <= mbytes) continue;
-            int rt = (int)((budget - mbytes) / tile_bytes);
+            if (budget <= fixed) continue;
+            int rt = (int)((budget - fixed) / tile_bytes);
             if (rt > max_rt) rt = max_rt;
             if (rt < 1) continue;
             if (wgs * rt > best_waves) { best_waves = wgs * rt; rt_out = rt; wgs_out = wgs; }
@@ -195,8 +196,13 @@ Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, bool bwd) 
     };
     Choice c{VAR_GLOBAL, 1, 1, false};
     int rt = 0, wgs = 1;
+    // single-wave tiles with gradient mirror and weight store in LDS
+    if (MT == 1 && fit(mirror_bytes + wstore_bytes, rt, wgs)) {
+        c.var = VAR_WAVE; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
+        return c;
+    }
     if (fit(mirror_bytes, rt, wgs)) {
-        c.var = MT > 1 ? VAR_GROUP : VAR_WAVE; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
+        c.var = VAR_GROUP; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
         return c;
     }
     if (fit(0, rt, wgs)) {   // tiles fit, the gradient mirror does not
@@ -229,6 +235,16 @@ int mirror_floats_of(int I, int O, int G, int P, bool sub) {
 // share the packed weights, so both must pick the same tile geometry. H = 2 (32-row tiles,
 // 8 lane columns per half) when every width is <= 8 channels, the algebra has the H = 2
 // kernels, and the backward layout still fits at least two row tiles beside the mirror.
+int wstore_floats_of(int I, int O, int G, bool sub) {
+    return (sub ? G : 1) * O * rup(I, 4) + 2 * G * O * rup(O, 4);
+}
+int wstore_total(int G, const csmpn_block_params* blocks, int nblk) {
+    int m = 0;
+    for (int k = 0; k < nblk; ++k)
+        m += rup(wstore_floats_of(blocks[k].in_features, blocks[k].out_features, G, blocks[k].lin_subspaces != 0), 4);
+    return m;
+}
+
 int mirror_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
     int m = 0;
     for (int k = 0; k < nblk; ++k)
@@ -244,8 +260,9 @@ int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
     const TileLayout Lb = tile_layout(D, 2, blocks, nblk, true, 0);
     const TileLayout Lf = tile_layout(D, 2, blocks, nblk, false, blocks[nblk - 1].out_features * D);
     const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
-    const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, true);
-    const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, false);
+    const size_t wst = (size_t)wstore_total(G, blocks, nblk) * 4;
+    const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, wst, true);
+    const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, wst, false);
     if (cb.var == VAR_WAVE && cb.rt * cb.wgs >= 2 && cf.var == VAR_WAVE && cf.rt * cf.wgs >= 2) return 2;
     return 1;
 }
@@ -285,7 +302,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     PD.G = G;
     PD.H = H;
     size_t cursor = 0;
-    int mirror = 0;
+    int mirror = 0, wstore = 0;
     auto add_seg = [&](const float* w, int O, int I, int has_grades, int transposed, int NT, int KK) -> const f4* {
         PackSeg& s = PD.seg[PD.nseg++];
         s.w = w; s.dst = ws + cursor; s.O = O; s.I = I; s.has_grades = has_grades; s.transposed = transposed;
@@ -311,7 +328,10 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         B.pbW1 = add_seg(b.lin_w, B.O, B.I, B.w1_sub, 1, B.NTi, B.KKo);
         B.pbWR = add_seg(b.right_w, B.O, B.O, 1, 1, B.NTo, B.KKo);
         B.pbWL = add_seg(b.left_w, B.O, B.O, 1, 1, B.NTo, B.KKo);
+        B.W1 = b.lin_w; B.WR = b.right_w; B.WL = b.left_w;
         B.lds_goff = mirror;
+        B.lds_woff = wstore;
+        wstore += rup(wstore_floats_of(B.I, B.O, G, B.w1_sub != 0), 4);
         mirror += rup(mirror_floats_of(B.I, B.O, G, P, B.w1_sub), 4);
         if (bwd) {
             if (!grads) return fail(CSMPN_ERR_INVALID, "grads is null");
@@ -328,17 +348,19 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     // buffers of one row tile (floats)
     const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen);
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
-    C.off_red = L.off_red; C.tile_floats = L.total;
+    C.off_red = L.off_red; C.off_idx = L.off_idx; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
 
     // choose the storage variant, row tiles per workgroup and workgroups per CU
-    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, bwd);
+    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, (size_t)wstore * 4, bwd);
+    if (H == 2 && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: H=2 without the single-wave variant");
     C.RT = ch.rt;
     plan.var = ch.var;
     C.mirror_floats = ch.mirror ? mirror : 0;
+    C.wstore_floats = ch.var == VAR_WAVE ? wstore : 0;
     if (ch.var != VAR_GLOBAL) {
         C.gtiles = nullptr;
-        plan.lds_bytes = (size_t)C.mirror_floats * 4 + (size_t)ch.rt * tile_bytes;
+        plan.lds_bytes = (size_t)(C.mirror_floats + C.wstore_floats) * 4 + (size_t)ch.rt * tile_bytes;
         plan.grid_cap = 256u * (unsigned)ch.wgs;
     } else {
         // tiles too large for the LDS: keep them in a global scratch behind the packed weights
@@ -354,15 +376,19 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
 }
 
 int run_pack(const Plan& plan, hipStream_t st) {
-    if (plan.P.total == 0) return CSMPN_OK;
+    if (plan.P.total == 0 || plan.var == VAR_WAVE) return CSMPN_OK;   // VAR_WAVE stages raw weights in LDS
     const unsigned block = 256, grid = (unsigned)((plan.P.total + block - 1) / block);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid), dim3(block), 0, st, plan.P);
     HIP_TRY(hipGetLastError());
     return CSMPN_OK;
 }
 
-int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, hipStream_t st) {
-    if (io.rows <= 0) return CSMPN_OK;
+unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of cycle accumulators
+
+int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st) {
+    if (io_in.rows <= 0) return CSMPN_OK;
+    RowIO io = io_in;
+    io.stamps = g_stamps;
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
     long grid = (ntiles + plan.C.RT - 1) / plan.C.RT;
@@ -436,6 +462,9 @@ __global__ void csr_canon_kernel(const int* row_ptr, long N, int* perm, int* src
 extern "C" {
 
 const char* csmpn_last_error(void) { return g_err; }
+
+/* diagnostic (-DCSMPN_STAMPS builds): device buffer of 25 uint64 per-phase cycle sums + wave count */
+void csmpn_debug_set_stamps(void* device_u64x25) { g_stamps = static_cast<unsigned long long*>(device_u64x25); }
 int csmpn_abi_version(void) { return 1; }
 const char* csmpn_build_target(void) { return "gfx950"; }
 
@@ -518,8 +547,8 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
     // edge-forward staging row
     const TileLayout Lb = tile_layout(D, 1, blocks, n_blocks, true, 0);
     const TileLayout Lf = tile_layout(D, 1, blocks, n_blocks, false, blocks[n_blocks - 1].out_features * D);
-    const Choice cb = choose_variant(MT, (size_t)Lb.total * 4, 0, true);
-    const Choice cf = choose_variant(MT, (size_t)Lf.total * 4, 0, false);
+    const Choice cb = choose_variant(MT, (size_t)Lb.total * 4, 0, 0, true);
+    const Choice cf = choose_variant(MT, (size_t)Lf.total * 4, 0, 0, false);
     size_t scratch = 0;
     if (cb.var == VAR_GLOBAL) scratch = (size_t)kGlobalTileGrid * cb.rt * Lb.total * 4;
     if (cf.var == VAR_GLOBAL) {

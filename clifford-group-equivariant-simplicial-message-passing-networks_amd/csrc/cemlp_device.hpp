@@ -52,8 +52,10 @@ struct DevBlock {
     int CPi, CPo;        // channels padded to a multiple of 4
     int has_b1;          // MVLinear bias present
     int lds_goff;        // float offset of this block's gradient mirror in LDS
+    int lds_woff;        // float offset of this block's weight store in LDS (VAR_WAVE)
     int w1_sub;          // 1: W1 is [O,I,G]; 0: [O,I]
-    int pad_;
+    // dense weights, reference layouts (staged into LDS by the VAR_WAVE kernels)
+    const float *W1, *WR, *WL;
     // small parameters, reference layouts
     const float *b1, *sa, *sb, *w, *an, *bL, *la;
     // packed weight fragments (f4 per lane): forward [nt][kk][hp][g][64], transposed [it][kk][hp][g][64]
@@ -67,9 +69,11 @@ struct DevCemlp {
     int MT;              // waves cooperating on one row tile = ceil(max O / NW)
     int RT;              // row tiles per workgroup
     int H;               // row halves per tile (1 or 2)
-    int off_in, off_p0, off_p1, off_z, off_g, off_red;  // float offsets inside one row tile's buffers
+    int off_in, off_p0, off_p1, off_z, off_g, off_red, off_idx;  // float offsets inside one row tile's buffers
     int tile_floats;     // floats per row tile
     int mirror_floats;   // LDS floats of the gradient mirror (0 if not used)
+    int wstore_floats;   // LDS floats of the weight store (VAR_WAVE, else 0)
+    int pad_;
     float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
     DevBlock b[4];
 };
@@ -104,6 +108,7 @@ struct RowIO {
     float* gx[3];           // per segment gradient target (nullable)
     int resid_bwd;          // NODE: add gy to gx[0]
     int pad2_;
+    unsigned long long* stamps;   // diagnostic (-DCSMPN_STAMPS) cycle accumulators, else null
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use
@@ -130,7 +135,25 @@ struct Geo {
         h = H == 1 ? 0 : (n >> 3);
         cn = H == 1 ? n : (n & 7);
         r0 = 16 * h + 4 * q;                // first of the lane's 4 rows
+#ifdef CSMPN_STAMPS
+        for (int i = 0; i < kStampSlots; ++i) acc[i] = 0;
+        t0 = __builtin_amdgcn_s_memtime();
+#endif
     }
+#ifdef CSMPN_STAMPS
+    // diagnostic build only: shader-clock cycles per phase, summed per wave
+    static constexpr int kStampSlots = 24;
+    mutable unsigned long long t0, acc[kStampSlots];
+    CSMPN_DEV void stamp(int id) const {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        acc[id] += t1 - t0;
+        t0 = t1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    CSMPN_DEV void stamp(int) const {}
+#endif
 };
 
 // ---------------------------------------------------------------------------------
@@ -162,6 +185,19 @@ CSMPN_DEV f4 chan_sum4(f4 v) {
     return f4{chan_sum<H>(v.x), chan_sum<H>(v.y), chan_sum<H>(v.z), chan_sum<H>(v.w)};
 }
 CSMPN_DEV float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+// sum over all lanes that hold the same channel: the 4 row-quarters (lanes l^32 by
+// ds_bpermute, l^16 by ds_swizzle: the LDS crossbar, no memory access) and, for
+// H = 2, the two row halves (lane columns n and n^8: one DPP rotate). Result in every lane.
+template <int H>
+CSMPN_DEV float channel_rows_sum(float v) {
+    // lanes l and l^32: ds_bpermute (hipcc mis-selects the second result of
+    // __builtin_amdgcn_permlane32_swap when both operands carry the same value)
+    const float s = v + __shfl_xor(v, 32);
+    // swizzle, bit-mask mode: and 0x1F, or 0, xor 0x10  ->  lane ^ 16 inside each 32-lane group
+    float t = s + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), 0x401F));
+    if constexpr (H == 2) t += dpp_mov<0x128>(t);   // row_ror 8: the other half's column
+    return t;
+}
 
 // Accuracy: the parity bar is 1e-5 relative against the reference's fp32 CPU path. The
 // hardware approximations (v_rcp_f32, v_exp_f32, v_rsq_f32: ~1 ulp) are each refined by one
@@ -216,23 +252,62 @@ CSMPN_DEV void tile_sync() {
 // ---------------------------------------------------------------------------------
 // MFMA pieces
 
-// acc[d][v] += sum_in  T[in][d][row] * W[c][in][grade(d)]
-// tile: [channel][D][R] (channel stride CS); CP = valid channels (multiple of 4);
-// frags: [kk][hp][g][64] f4 for this wave's N tile
-template <class ALG, int H>
-CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, int KK, const f4* frags,
+// LDS weight store of one block (VAR_WAVE): three dense arrays [g][O][IP], IP = input
+// channels padded to 4 (padding zero-filled), so that a forward B fragment is ONE
+// ds_read_b128 and a transposed one four ds_read_b32 - no pre-packed, per-lane duplicated
+// fragments and no global-memory latency in front of the MFMAs.
+struct WOff { int W1, WR, WL, total; };
+CSMPN_DEV WOff wstore_offsets(int O, int CPi, int CPo, int G, bool w1_sub) {
+    WOff w;
+    w.W1 = 0;
+    w.WR = (w1_sub ? G : 1) * O * CPi;
+    w.WL = w.WR + G * O * CPo;
+    w.total = w.WL + G * O * CPo;
+    return w;
+}
+
+// where the B fragments of one linear come from
+struct WSrc {
+    const f4* frags;   // packed global fragments [nt][kk][hp][g][64] (barrier variants)
+    const float* w;    // LDS array [g][O][IP] (VAR_WAVE)
+    int O, IP;         // rows and row stride of w
+    int grades;        // 0: one matrix for all grades (MVLinear subspaces=False)
+};
+
+// acc[d][v] += sum_in  T[in][d][row] * W[out][in][grade(d)]        (TRANS = false)
+// acc[d][v] += sum_out T[out][d][row] * W[out][in][grade(d)]       (TRANS = true, acc over in)
+// tile: [channel][D][R] (channel stride CS); CP = valid channels (multiple of 4); nt = this
+// wave's N tile; KK = k-blocks of 16 contracted channels.
+template <class ALG, int H, bool WLDS, bool TRANS>
+CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, int KK, const WSrc& ws, int nt,
                                 const Geo<ALG, H>& ge) {
     using GE = Geo<ALG, H>;
-    constexpr int G = ALG::G, R = GE::R, CS = GE::CS;
+    constexpr int G = ALG::G, R = GE::R, CS = GE::CS, NW = GE::NW;
+    const f4* fbase = ws.frags + (size_t)nt * KK * (H * G * 64) + ge.lane;
+    const int ncol = NW * nt + ge.cn;   // this lane's output channel of the product
     for (int kk = 0; kk < KK; ++kk) {
         const int c0 = 16 * kk + 4 * ge.q;
         const bool valid = c0 < CP;
         const float* ap = tile + c0 * CS + ge.n;
-        const f4* fp = frags + (size_t)kk * (H * G * 64) + ge.lane;
 #pragma unroll
         for (int hp = 0; hp < H; ++hp) {
             static_for<0, G>([&](auto g) {
-                const f4 b = fp[(hp * G + g) * 64];
+                f4 b;
+                if constexpr (!WLDS) {
+                    b = fbase[(size_t)kk * (H * G * 64) + (hp * G + g) * 64];
+                } else {
+                    const int gi = ws.grades ? int(g) : 0;
+                    const bool half_ok = H == 1 || ge.h == hp;
+                    if constexpr (!TRANS) {
+                        const bool ok = half_ok && ncol < ws.O && c0 < ws.IP;
+                        b = ok ? *reinterpret_cast<const f4*>(ws.w + (gi * ws.O + ncol) * ws.IP + c0) : splat(0.f);
+                    } else {
+                        const float* wp = ws.w + (gi * ws.O + c0) * ws.IP + ncol;
+                        const bool ok = half_ok && ncol < ws.IP;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) b[v] = (ok && c0 + v < ws.O) ? wp[v * ws.IP] : 0.f;
+                    }
+                }
                 constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -445,20 +520,25 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 // red: scratch [MT][16] floats for cross-wave LayerNorm sums (barrier variants only).
 template <class ALG, int H, int VAR>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
-                             float* red, int MT, int mt, const Geo<ALG, H>& ge, FwdState<ALG>& S,
-                             f4 (&out)[ALG::D]) {
+                             float* red, const float* wstore, int MT, int mt, const Geo<ALG, H>& ge,
+                             FwdState<ALG>& S, f4 (&out)[ALG::D]) {
     using GE = Geo<ALG, H>;
     static_assert(H == 1 || !kVarBarrier<VAR>, "multi-wave row tiles use H = 1");
     constexpr int D = ALG::D, G = ALG::G, NW = GE::NW;
     const int c = NW * mt + ge.cn;
     const bool tile_active = NW * mt < B.O;
-    const size_t fstride = (size_t)H * G * 64;   // f4 per (N tile, k-block)
+    constexpr bool WLDS = VAR == VAR_WAVE;
+    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+    const WSrc sW1{B.pfW1, wstore + B.lds_woff + wo.W1, B.O, B.CPi, B.w1_sub};
+    const WSrc sWR{B.pfWR, wstore + B.lds_woff + wo.WR, B.O, B.CPo, 1};
+    const WSrc sWL{B.pfWL, wstore + B.lds_woff + wo.WL, B.O, B.CPo, 1};
 
     // 1. MVLinear (cegnn_utils.py:326-338)
 #pragma unroll
     for (int d = 0; d < D; ++d) S.y[d] = splat(0.f);
-    if (tile_active) linear_from_tile<ALG, H>(S.y, xin, B.CPi, B.KKi, B.pfW1 + mt * fstride * B.KKi, ge);
+    if (tile_active) linear_from_tile<ALG, H, WLDS, false>(S.y, xin, B.CPi, B.KKi, sW1, mt, ge);
     S.y[0] += lp.b1;
+    ge.stamp(3);
 
     CSMPN_PHASE();
     // 2. MVSiLU, invariant "mag2" (cegnn_utils.py:76-83)
@@ -481,6 +561,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     });
     store_tile<ALG, H>(z, zbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
+    ge.stamp(4);
 
     CSMPN_PHASE();
     // 3. linear_right / linear_left (cegnn_utils.py:143-148)
@@ -488,10 +569,11 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 #pragma unroll
     for (int d = 0; d < D; ++d) { S.R[d] = splat(0.f); L[d] = splat(0.f); }
     if (tile_active) {
-        linear_from_tile<ALG, H>(S.R, zbuf, B.CPo, B.KKo, B.pfWR + mt * fstride * B.KKo, ge);
-        linear_from_tile<ALG, H>(L, zbuf, B.CPo, B.KKo, B.pfWL + mt * fstride * B.KKo, ge);
+        linear_from_tile<ALG, H, WLDS, false>(S.R, zbuf, B.CPo, B.KKo, sWR, mt, ge);
+        linear_from_tile<ALG, H, WLDS, false>(L, zbuf, B.CPo, B.KKo, sWL, mt, ge);
     }
     L[0] += lp.bL;
+    ge.stamp(5);
 
     CSMPN_PHASE();
     // 4. NormalizationLayer on the right operand (cegnn_utils.py:42-51)
@@ -509,12 +591,14 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
         for (int t = 0; t < nd; ++t) r[d0 + t] = S.R[d0 + t] * S.invden[g];
     });
 
+    ge.stamp(6);
     CSMPN_PHASE();
     // 5. steerable geometric product + first-order term (cegnn_utils.py:126-152)
     if (lp.cvalid) weighted_gp<ALG>(L, z, r, B.w + (size_t)c * ALG::P);
 #pragma unroll
     for (int d = 0; d < D; ++d) S.s[d] = L[d] * kInvSqrt2;
 
+    ge.stamp(7);
     CSMPN_PHASE();
     // 6. MVLayerNorm (cegnn_utils.py:93-96): mean over the channels of the row
     f4 qs = splat(0.f);
@@ -535,6 +619,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     S.invMn = rcp4(tot * (1.0f / float(B.O)) + kEps);
 #pragma unroll
     for (int d = 0; d < D; ++d) out[d] = lp.la * S.s[d] * S.invMn;
+    ge.stamp(8);
 }
 
 // ---------------------------------------------------------------------------------
@@ -544,15 +629,18 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 template <class ALG, int H, int VAR>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
-                              float* red, float* mirror, int MT, int mt, const Geo<ALG, H>& ge,
-                              f4 (&gy)[ALG::D]) {
+                              float* red, float* mirror, const float* wstore, int MT, int mt,
+                              const Geo<ALG, H>& ge, f4 (&gy)[ALG::D]) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P, NW = GE::NW;
     const int c = NW * mt + ge.cn;
     const bool tile_active = NW * mt < B.O;
     const bool cv = lp.cvalid;
     const int cc = cv ? c : 0;
-    const size_t fstride = (size_t)H * G * 64;
+    constexpr bool WLDS = VAR == VAR_WAVE;
+    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+    const WSrc sWRt{B.pbWR, wstore + B.lds_woff + wo.WR, B.O, B.CPo, 1};
+    const WSrc sWLt{B.pbWL, wstore + B.lds_woff + wo.WL, B.O, B.CPo, 1};
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, P, B.w1_sub != 0);
     float* mir = mirror + B.lds_goff;
     // gradient destinations: LDS mirror (flushed once per workgroup) or, in the variants
@@ -593,6 +681,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         ggp[d] = cv ? gs * kInvSqrt2 : splat(0.f);
     });
     p_bL = hsum(ggp[0]);
+    ge.stamp(9);
 
     CSMPN_PHASE();
     // ---- d/dz from linear_left: gz = GL . WL^T ; gWL += GL (x) Z
@@ -602,10 +691,11 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
 #pragma unroll
     for (int d = 0; d < D; ++d) gz[d] = splat(0.f);
     if (tile_active) {
-        linear_from_tile<ALG, H>(gz, gbuf, B.CPo, B.KKo, B.pbWL + mt * fstride * B.KKo, ge);
+        linear_from_tile<ALG, H, WLDS, true>(gz, gbuf, B.CPo, B.KKo, sWLt, mt, ge);
         weight_grad<ALG, H, in_lds>(ggp, zbuf, B.CPo, B.O, B.O, B.NTo, mt, ge, d_WL, true);
     }
 
+    ge.stamp(10);
     CSMPN_PHASE();
     // ---- geometric product backward
     f4 gr[D];
@@ -615,6 +705,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     for (int p = 0; p < P; ++p) p_w[p] = 0.f;
     if (tile_active) weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, B.w + (size_t)cc * P, gz, gr, p_w);
 
+    ge.stamp(11);
     CSMPN_PHASE();
     // ---- NormalizationLayer backward -> gR (q_g and nu_g are rebuilt from R)
     f4 gR[D];
@@ -636,14 +727,16 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
             gR[d] = cv ? gr[d] * S.invden[g] + gq * (2.0f * qsf<ALG, d>) * S.R[d] : splat(0.f);
         });
     });
+    ge.stamp(12);
     tile_sync<VAR>();   // all reads of gbuf (GL) done
     store_tile<ALG, H>(gR, gbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
     if (tile_active) {
-        linear_from_tile<ALG, H>(gz, gbuf, B.CPo, B.KKo, B.pbWR + mt * fstride * B.KKo, ge);
+        linear_from_tile<ALG, H, WLDS, true>(gz, gbuf, B.CPo, B.KKo, sWRt, mt, ge);
         weight_grad<ALG, H, in_lds>(gR, zbuf, B.CPo, B.O, B.O, B.NTo, mt, ge, d_WR, true);
     }
 
+    ge.stamp(13);
     CSMPN_PHASE();
     // ---- MVSiLU backward -> gy
     static_for<0, G>([&](auto g) {
@@ -674,12 +767,24 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         });
     });
     p_b1 = hsum(gy[0]);
+    ge.stamp(14);
 
     CSMPN_PHASE();
-    // ---- small-parameter gradients: one predicated region, every lane of the channel adds
-    // its 4-row partial (the 4*H lanes of a channel hit one address; the LDS atomic unit
-    // serialises them, which is cheaper than cross-lane reductions plus per-value branches)
-    if (cv) {
+    // ---- small-parameter gradients: reduce the per-lane partials over the lanes of the
+    // channel with permlane swaps (no LDS, no bank conflicts), then ONE lane per channel adds
+    // them in a single predicated region (conflict-free atomics)
+    p_la = channel_rows_sum<H>(p_la);
+    p_bL = channel_rows_sum<H>(p_bL);
+    p_b1 = channel_rows_sum<H>(p_b1);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        p_an[g] = channel_rows_sum<H>(p_an[g]);
+        p_sa[g] = channel_rows_sum<H>(p_sa[g]);
+        p_sb[g] = channel_rows_sum<H>(p_sb[g]);
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) p_w[p] = channel_rows_sum<H>(p_w[p]);
+    if (cv && ge.q == 0 && ge.h == 0) {
         atomicAdd(d_la + c, p_la);
         atomicAdd(d_bL + c, p_bL);
         if (B.has_b1) atomicAdd(d_b1 + c, p_b1);
@@ -700,6 +805,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     store_tile<ALG, H>(gy, gbuf, B.CPo, mt, ge);
     if (tile_active) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
     tile_sync<VAR>();
+    ge.stamp(16);
 }
 
 // flush one block's LDS gradient mirror into the global reference-layout accumulators

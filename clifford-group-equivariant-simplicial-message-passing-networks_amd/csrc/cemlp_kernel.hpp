@@ -15,7 +15,7 @@ namespace csmpn {
 // so the LDS writes are conflict-free; the global reads are 16-byte pieces of R different
 // rows (the rows of a tile are L2-resident neighbours after the CSR sort).
 template <class ALG, int H>
-__device__ void stage_input(const RowIO& io, float* tile, int CP, long row0, int tid, int nthreads) {
+__device__ void stage_input(const RowIO& io, float* tile, int* tidx, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
     constexpr int DQ = D / 4;   // float4 chunks per channel
@@ -32,6 +32,12 @@ __device__ void stage_input(const RowIO& io, float* tile, int CP, long row0, int
             ra = sg.ia ? (long)sg.ia[grow] : grow;
             if (sg.b) rb = sg.ib ? (long)sg.ib[grow] : grow;
             if (sg.deg) { const int dg = sg.deg[ra]; scale = 1.0f / float(dg > 1 ? dg : 1); }
+        }
+        // keep the gathered row indices of this tile in LDS: the scatter / gradient gather of
+        // the same tile reuse them instead of issuing dependent global loads per row
+        if (grp == 0 && s < 2) {
+            if (s == 0) { tidx[row] = rvalid ? (int)ra : -1; tidx[R + row] = rvalid ? (int)rb : -1; }
+            else tidx[2 * R + row] = rvalid ? (int)ra : -1;
         }
         const float* pa = sg.a + ra * sg.ch * D;
         const float* pb = sg.b ? sg.b + rb * sg.ch * D : nullptr;
@@ -71,11 +77,12 @@ CSMPN_DEV void store_dense(const f4 (&t)[ALG::D], float* stage, int nch, int ch,
     }
 }
 
-// rows of a dense staged tile -> atomic adds into table rows selected by idx (sign * value).
-// SEGMENTED (single-wave tiles, rows sorted by idx): equal consecutive targets are summed first.
+// rows of a dense staged tile -> atomic adds into table rows selected by lidx (LDS copy of
+// the tile's row indices, -1 = masked row), sign * value.
+// SEGMENTED (single-wave tiles, rows sorted by index): equal consecutive targets are summed first.
 template <class ALG, int H, bool SEGMENTED>
-__device__ void scatter_rows(const float* stage, int rowlen, const int* idx, long row0, long rows, float* table,
-                             float sign, int tid, int nthreads) {
+__device__ void scatter_rows(const float* stage, int rowlen, const int* lidx, float* table, float sign, int tid,
+                             int nthreads) {
     constexpr int D = ALG::D, R = 16 * H;
     if constexpr (SEGMENTED) {
         constexpr int NPER = D / 4;   // rowlen <= 16*D  ->  <= D/4 elements per lane
@@ -84,9 +91,8 @@ __device__ void scatter_rows(const float* stage, int rowlen, const int* idx, lon
         for (int j = 0; j < NPER; ++j) acc[j] = 0.f;
         int cur = -1;
         for (int row = 0; row < R; ++row) {
-            const long grow = row0 + row;
-            if (grow >= rows) break;
-            const int target = __builtin_amdgcn_readfirstlane(idx[grow]);
+            const int target = __builtin_amdgcn_readfirstlane(lidx[row]);
+            if (target < 0) break;
             if (target != cur) {
                 if (cur >= 0) {
 #pragma unroll
@@ -113,18 +119,38 @@ __device__ void scatter_rows(const float* stage, int rowlen, const int* idx, lon
         }
     } else {
         for (int row = 0; row < R; ++row) {
-            const long grow = row0 + row;
-            if (grow >= rows) break;
-            const long target = idx[grow];
+            const long target = lidx[row];
+            if (target < 0) break;
             for (int f = tid; f < rowlen; f += nthreads) atomicAdd(table + target * rowlen + f, sign * stage[row * rowlen + f]);
         }
+    }
+}
+
+// copy one block's dense weights (reference layout [O][I][G] or [O][I]) into the LDS store
+// [g][O][IP]; padding columns were zero-filled by the caller
+__device__ inline void stage_weight(const float* w, float* dst, int O, int I, int IP, int G, bool grades, int tid,
+                                    int nthreads) {
+    const int per = I * (grades ? G : 1);
+    for (int e = tid; e < O * per; e += nthreads) {
+        const int o = e / per, rem = e - o * per;
+        const int i = grades ? rem / G : rem, g = grades ? rem - i * G : 0;
+        dst[(g * O + o) * IP + i] = w[e];
     }
 }
 
 // Forward: 512 threads (2 waves/SIMD at <=256 VGPRs). Backward keeps the whole forward
 // state of a block live: 256 threads (1 wave/SIMD, up to 512 VGPRs).
 template <class ALG, int MODE, int VAR, int H, bool BWD>
-__global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C, const RowIO io) {
+__global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+    // Read the descriptors in place from the kernarg segment (constant address space, scalar
+    // loads). Indexing the by-value arguments dynamically (C.b[k]) makes the compiler copy
+    // the whole struct to scratch and turns every field access into a scratch load.
+    typedef const char __attribute__((address_space(4))) * KArgPtr;
+    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
+    const DevCemlp& C = *(const DevCemlp*)(const char*)ka;
+    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
+    (void)C_arg; (void)io_arg;
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, G = ALG::G, R = GE::R, NW = GE::NW;
     constexpr bool MULTI = kVarBarrier<VAR>;
@@ -136,19 +162,33 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
     const int rt = wave / MT, mt = wave - rt * MT;
     const int tid_rt = mt * 64 + lane, nthr_rt = MT * 64;
     const GE ge(lane);
+    constexpr bool WLDS = VAR == VAR_WAVE;
     float* mirror = smem;
+    float* wstore = smem + C.mirror_floats;
     float* base;
     if constexpr (GT) base = C.gtiles + ((size_t)blockIdx.x * RT + rt) * C.tile_floats;
-    else base = smem + C.mirror_floats + (size_t)rt * C.tile_floats;
+    else base = smem + C.mirror_floats + C.wstore_floats + (size_t)rt * C.tile_floats;
     float* buf_in = base + C.off_in;
     auto buf_p = [&](int i) -> float* { return base + ((i & 1) ? C.off_p1 : C.off_p0); };
     float* buf_z = base + C.off_z;
     float* buf_g = base + C.off_g;
     float* red = base + C.off_red;
-    const size_t fstride = (size_t)H * G * 64;
+    int* tidx = reinterpret_cast<int*>(base + C.off_idx);
 
-    if constexpr (BWD && in_lds) {
-        for (int e = threadIdx.x; e < C.mirror_floats; e += blockDim.x) mirror[e] = 0.f;
+    if constexpr ((BWD && in_lds) || WLDS) {
+        // zero the gradient mirror and the weight store (its padding columns stay zero)
+        for (int e = threadIdx.x; e < C.mirror_floats + C.wstore_floats; e += blockDim.x) smem[e] = 0.f;
+        __syncthreads();
+    }
+    if constexpr (WLDS) {
+        for (int k = 0; k < C.nblk; ++k) {
+            const DevBlock& B = C.b[k];
+            const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+            float* ws = wstore + B.lds_woff;
+            stage_weight(B.W1, ws + wo.W1, B.O, B.I, B.CPi, G, B.w1_sub != 0, threadIdx.x, blockDim.x);
+            stage_weight(B.WR, ws + wo.WR, B.O, B.O, B.CPo, G, true, threadIdx.x, blockDim.x);
+            stage_weight(B.WL, ws + wo.WL, B.O, B.O, B.CPo, G, true, threadIdx.x, blockDim.x);
+        }
         __syncthreads();
     }
 
@@ -161,8 +201,9 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
     for (long iter = 0; iter < niter; ++iter) {
         const long tile = iter * tiles_per_iter + (long)blockIdx.x * RT + rt;
         const long row0 = tile * R;   // may be >= rows: fully masked tile
-        stage_input<ALG, H>(io, buf_in, B0.CPi, row0, tid_rt, nthr_rt);
+        stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
         tile_sync<VAR>();
+        ge.stamp(0);
 
         if constexpr (!BWD) {
             // ------------------------------------------------------------ forward
@@ -172,7 +213,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 const DevBlock& B = C.b[k];
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, NW * mt + ge.cn);
                 FwdState<ALG> S;
-                block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, MT, mt, ge, S, out);
+                block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, out);
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR>();
                     store_tile<ALG, H>(out, buf_p(k), B.CPo, mt, ge);
@@ -186,8 +227,9 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 tile_sync<VAR>();
                 store_dense<ALG, H>(out, buf_g, O, c, ge);
                 tile_sync<VAR>();
-                scatter_rows<ALG, H, !MULTI>(buf_g, O * D, io.dst, row0, io.rows, io.agg, 1.0f, tid_rt, nthr_rt);
+                scatter_rows<ALG, H, !MULTI>(buf_g, O * D, tidx, io.agg, 1.0f, tid_rt, nthr_rt);
                 tile_sync<VAR>();
+                ge.stamp(18);
             } else {
                 if (c < O) {
 #pragma unroll
@@ -217,7 +259,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     const long grow = row0 + ge.r0 + v;
                     const bool ok = grow < io.rows && c < OL;
                     long srow = grow;
-                    if (MODE == MODE_EDGE && ok) srow = io.dst[grow];
+                    if (MODE == MODE_EDGE && ok) srow = tidx[ge.r0 + v];
                     const float* p = io.gy + (srow * OL + c) * D;
 #pragma unroll
                     for (int d4 = 0; d4 < D; d4 += 4) {
@@ -226,6 +268,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     }
                 }
             }
+            ge.stamp(1);
             for (int k = C.nblk - 1; k >= 0; --k) {
                 const DevBlock& B = C.b[k];
                 // recompute the input tile of block k
@@ -235,10 +278,11 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     const LaneParams<ALG> lpj = load_lane_params<ALG>(Bj, NW * mt + ge.cn);
                     FwdState<ALG> Sj;
                     f4 oj[D];
-                    block_forward<ALG, H, VAR>(Bj, lpj, in, buf_z, red, MT, mt, ge, Sj, oj);
+                    block_forward<ALG, H, VAR>(Bj, lpj, in, buf_z, red, wstore, MT, mt, ge, Sj, oj);
                     tile_sync<VAR>();
                     store_tile<ALG, H>(oj, buf_p(j), Bj.CPo, mt, ge);
                     tile_sync<VAR>();
+                    ge.stamp(2);
                     in = buf_p(j);
                 }
                 const LaneParams<ALG> lp = load_lane_params<ALG>(B, NW * mt + ge.cn);
@@ -246,16 +290,19 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 {
                     FwdState<ALG> S;
                     f4 unused[D];
-                    block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, MT, mt, ge, S, unused);
-                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, MT, mt, ge, gy);
+                    block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused);
+                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy);
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
+                const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+                const WSrc sW1t{B.pbW1, wstore + B.lds_woff + wo.W1, B.O, B.CPi, B.w1_sub};
                 if (k > 0) {
 #pragma unroll
                     for (int d = 0; d < D; ++d) gout[d] = splat(0.f);
                     if (mt < B.NTi)
-                        linear_from_tile<ALG, H>(gout, buf_g, B.CPo, B.KKo, B.pbW1 + mt * fstride * B.KKo, ge);
+                        linear_from_tile<ALG, H, WLDS, true>(gout, buf_g, B.CPo, B.KKo, sW1t, mt, ge);
                     tile_sync<VAR>();
+                    ge.stamp(17);
                 } else {
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
                     const int Cs0 = io.seg[0].ch;
@@ -263,7 +310,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                         f4 gx[D];
 #pragma unroll
                         for (int d = 0; d < D; ++d) gx[d] = splat(0.f);
-                        linear_from_tile<ALG, H>(gx, buf_g, B.CPo, B.KKo, B.pbW1 + it * fstride * B.KKo, ge);
+                        linear_from_tile<ALG, H, WLDS, true>(gx, buf_g, B.CPo, B.KKo, sW1t, it, ge);
                         const int i = NW * it + ge.cn;
                         // which input segment does channel i belong to
                         int s = -1;
@@ -279,7 +326,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                                 const long grow = row0 + ge.r0 + v;
                                 if (grow < io.rows) {
                                     long trow = grow;
-                                    if (MODE == MODE_EDGE) trow = io.perm[grow];   // edge_attr lives in original order
+                                    if (MODE == MODE_EDGE) trow = tidx[2 * R + ge.r0 + v];   // edge_attr lives in original order
                                     float scale = 1.0f;
                                     if (sg.deg) { const int dg = sg.deg[grow]; scale = 1.0f / float(dg > 1 ? dg : 1); }
                                     float* p = io.gx[s] + (trow * sg.ch + ci) * D;
@@ -294,14 +341,16 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                             }
                         }
                     }
+                    ge.stamp(17);
                     if constexpr (MODE == MODE_EDGE) {
                         tile_sync<VAR>();
                         if (io.gx[0]) {
-                            scatter_rows<ALG, H, !MULTI>(stage, Cs0 * D, io.dst, row0, io.rows, io.gx[0], 1.0f, tid_rt, nthr_rt);
-                            scatter_rows<ALG, H, false>(stage, Cs0 * D, io.src, row0, io.rows, io.gx[0], -1.0f, tid_rt, nthr_rt);
+                            scatter_rows<ALG, H, !MULTI>(stage, Cs0 * D, tidx, io.gx[0], 1.0f, tid_rt, nthr_rt);
+                            scatter_rows<ALG, H, false>(stage, Cs0 * D, tidx + R, io.gx[0], -1.0f, tid_rt, nthr_rt);
                         }
                     }
                     tile_sync<VAR>();
+                    ge.stamp(18);
                 }
             }
         }
@@ -311,6 +360,13 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         __syncthreads();
         for (int k = 0; k < C.nblk; ++k) flush_mirror<ALG>(C.b[k], mirror, threadIdx.x, blockDim.x);
     }
+#ifdef CSMPN_STAMPS
+    ge.stamp(19);
+    if (io.stamps && lane == 0) {
+        for (int i = 0; i < GE::kStampSlots; ++i) atomicAdd(io.stamps + i, ge.acc[i]);
+        atomicAdd(io.stamps + GE::kStampSlots, 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
