@@ -285,10 +285,13 @@ CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, in
     constexpr int G = ALG::G, R = GE::R, CS = GE::CS, NW = GE::NW;
     const f4* fbase = ws.frags + (size_t)nt * KK * (H * G * 64) + ge.lane;
     const int ncol = NW * nt + ge.cn;   // this lane's output channel of the product
+    // All LDS reads below are UNCONDITIONAL from clamped (always valid, finite) addresses:
+    // a k-slot beyond the tile's channels contributes nothing because its B fragment (the
+    // weight) is zero there. Predicated reads would compile to an exec-mask branch plus a
+    // full s_waitcnt in front of every single MFMA.
     for (int kk = 0; kk < KK; ++kk) {
         const int c0 = 16 * kk + 4 * ge.q;
-        const bool valid = c0 < CP;
-        const float* ap = tile + c0 * CS + ge.n;
+        const float* ap = tile + (c0 < CP ? c0 : 0) * CS + ge.n;
 #pragma unroll
         for (int hp = 0; hp < H; ++hp) {
             static_for<0, G>([&](auto g) {
@@ -299,24 +302,29 @@ CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, in
                     const int gi = ws.grades ? int(g) : 0;
                     const bool half_ok = H == 1 || ge.h == hp;
                     if constexpr (!TRANS) {
-                        const bool ok = half_ok && ncol < ws.O && c0 < ws.IP;
-                        b = ok ? *reinterpret_cast<const f4*>(ws.w + (gi * ws.O + ncol) * ws.IP + c0) : splat(0.f);
+                        const float okf = (half_ok && ncol < ws.O && c0 < ws.IP) ? 1.0f : 0.0f;
+                        const int oc = ncol < ws.O ? ncol : 0, ic = c0 < ws.IP ? c0 : 0;
+                        b = *reinterpret_cast<const f4*>(ws.w + (gi * ws.O + oc) * ws.IP + ic) * okf;
                     } else {
-                        const float* wp = ws.w + (gi * ws.O + c0) * ws.IP + ncol;
-                        const bool ok = half_ok && ncol < ws.IP;
+                        const bool okc = half_ok && ncol < ws.IP;
+                        const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) b[v] = (ok && c0 + v < ws.O) ? wp[v * ws.IP] : 0.f;
+                        for (int v = 0; v < 4; ++v) {
+                            const int o = c0 + v;
+                            b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                        }
                     }
                 }
                 constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+                float a[4][nd];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
+                for (int v = 0; v < 4; ++v)
 #pragma unroll
-                    for (int t = 0; t < nd; ++t) {
-                        const float a = valid ? ap[v * CS + (d0 + t) * R + 16 * hp] : 0.f;
-                        acc[d0 + t] = mfma16(a, b[v], acc[d0 + t]);
-                    }
-                }
+                    for (int t = 0; t < nd; ++t) a[v][t] = ap[v * CS + (d0 + t) * R + 16 * hp];
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int t = 0; t < nd; ++t) acc[d0 + t] = mfma16(a[v][t], b[v], acc[d0 + t]);
             });
         }
     }
@@ -337,15 +345,16 @@ CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int CP, in
     const int ob = NW * mt + (H == 1 ? 4 * ge.q : 4 * (ge.q & 1));
     for (int it = 0; it < NTin; ++it) {
         const int cin = NW * it + ge.cn;
-        const bool cvalid = cin < CP;
-        const float* bp = tile + cin * CS + ge.r0;
+        // clamped, unconditional read: columns cin >= CP produce garbage outputs that the
+        // bounds check below discards
+        const float* bp = tile + (cin < CP ? cin : 0) * CS + ge.r0;
         f4 accg[G];
         static_for<0, G>([&](auto g) {
             f4 acc = splat(0.f);
             constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
 #pragma unroll
             for (int t = 0; t < nd; ++t) {
-                const f4 b = cvalid ? *reinterpret_cast<const f4*>(bp + (d0 + t) * R) : splat(0.f);
+                const f4 b = *reinterpret_cast<const f4*>(bp + (d0 + t) * R);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) acc = mfma16(gr[d0 + t][v], b[v], acc);
             }
