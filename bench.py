@@ -208,7 +208,7 @@ def main():
         out, st_n = be.node_forward(spec, deg, hd, agg, na, pn)
         gh, g_agg, _, _ = be.node_backward(spec, deg, hd, agg, na, pn, gout, False, st_n)
         stages = {
-            "edge_fwd": lambda: be.edge_forward(spec, csr, hd, ea, pe),
+            "edge_fwd": lambda: be.edge_forward(spec, csr, hd, ea, pe),   # incl. saving block inputs
             "node_fwd": lambda: be.node_forward(spec, deg, hd, agg, na, pn),
             "node_bwd": lambda: be.node_backward(spec, deg, hd, agg, na, pn, gout, False, st_n),
             "edge_bwd": lambda: be.edge_backward(spec, csr, hd, ea, pe, g_agg, gh, False, st_e),

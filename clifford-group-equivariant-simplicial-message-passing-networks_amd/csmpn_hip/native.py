@@ -21,6 +21,7 @@ EXPORTS = (
     "csmpn_geometric_product_forward",
     "csmpn_geometric_product_backward",
     "csmpn_cemlp_workspace_bytes",
+    "csmpn_cemlp_saved_floats_per_row",
     "csmpn_cemlp_forward",
     "csmpn_cemlp_backward",
     "csmpn_csr_build",
@@ -75,17 +76,18 @@ def _load():
     sig("csmpn_geometric_product_forward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, vp])
     sig("csmpn_geometric_product_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, i64, vp])
     sig("csmpn_cemlp_workspace_bytes", sz, [C.c_int, bp, C.c_int])
-    sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, sz, u32, vp])
-    sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, sz, u32, vp])
+    sig("csmpn_cemlp_saved_floats_per_row", sz, [C.c_int, bp, C.c_int])
+    sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp])
     sig("csmpn_egcl_edge_forward", C.c_int,
-        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, sz, u32, vp])
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_edge_backward", C.c_int,
-        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, sz, u32, vp])
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_node_forward", C.c_int,
-        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, sz, u32, vp])
+        [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_node_backward", C.c_int,
-        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, sz, u32, vp])
+        [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_last_error", C.c_char_p, [])
     sig("csmpn_abi_version", C.c_int, [])
     sig("csmpn_build_target", C.c_char_p, [])

@@ -62,6 +62,7 @@ class CemlpBinding:
         self._key = None
         self._grad_layout = None
         self._ws_bytes = None
+        self._saved_per_row = None
 
     def supported(self) -> bool:
         return bool(native.lib().csmpn_metric_supported(self.metric_arr, self.n))
@@ -81,6 +82,14 @@ class CemlpBinding:
             self._grad_layout = None
         if self._ws_bytes is None:
             self._ws_bytes = int(native.lib().csmpn_cemlp_workspace_bytes(self.n, self.params, self.nblk))
+
+    def new_saved(self, rows: int, device) -> Optional[torch.Tensor]:
+        """Buffer for the inputs of blocks 1.. (written by forward, read by backward)."""
+        if self._saved_per_row is None:
+            self._saved_per_row = int(native.lib().csmpn_cemlp_saved_floats_per_row(self.n, self.params, self.nblk))
+        if self._saved_per_row == 0 or rows == 0:
+            return None
+        return torch.empty(rows * self._saved_per_row, dtype=torch.float32, device=device)
 
     def workspace(self, device) -> torch.Tensor:
         return torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=device)
@@ -128,11 +137,12 @@ class _CemlpFn(torch.autograd.Function):
         rows = x.shape[0]
         y = torch.empty(rows, binding.out_features, binding.D, dtype=torch.float32, device=x.device)
         ws = binding.workspace(x.device)
+        saved = binding.new_saved(rows, x.device) if any(ctx.needs_input_grad) else None
         check(native.lib().csmpn_cemlp_forward(binding.metric_arr, binding.n, binding.params, binding.nblk,
-                                               x.data_ptr(), rows, y.data_ptr(), ws.data_ptr(), ws.numel(), 0,
-                                               _stream(x.device)))
+                                               x.data_ptr(), rows, y.data_ptr(), _ptr(saved), ws.data_ptr(),
+                                               ws.numel(), 0, _stream(x.device)))
         ctx.binding = binding
-        ctx.ws = ws   # packed weights are reused by backward
+        ctx.ws, ctx.saved = ws, saved   # packed weights / block inputs are reused by backward
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.mask = [p is not None for p in params]
         return y
@@ -150,7 +160,8 @@ class _CemlpFn(torch.autograd.Function):
         ws = ctx.ws
         check(native.lib().csmpn_cemlp_backward(binding.metric_arr, binding.n, binding.params, binding.grads,
                                                 binding.nblk, x.data_ptr(), gy.data_ptr(), x.shape[0], _ptr(gx),
-                                                ws.data_ptr(), ws.numel(), native.FLAG_WEIGHTS_PACKED,
+                                                _ptr(ctx.saved), ws.data_ptr(), ws.numel(),
+                                                native.FLAG_WEIGHTS_PACKED,
                                                 _stream(x.device)))
         return (gx, None, *views)
 
@@ -228,30 +239,33 @@ class HipBackend:
         return get_csr(edge_index, n_nodes)
 
     @staticmethod
-    def edge_forward(spec, csr, h, edge_attr, pe):
+    def edge_forward(spec, csr, h, edge_attr, pe, save=True):
+        """Returns (agg, state); state = (workspace with packed weights, saved block inputs)."""
         e = spec.edge
         e.bind(pe)
         N, D = h.shape[0], e.D
         agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
         ws = e.workspace(h.device)
+        saved = e.new_saved(csr.n_edges, h.device) if save else None
         check(native.lib().csmpn_egcl_edge_forward(
             e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
             csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(),
-            ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
-        return agg, ws
+            _ptr(saved), ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
+        return agg, (ws, saved)
 
     @staticmethod
-    def node_forward(spec, deg, h, agg, node_attr, pn):
+    def node_forward(spec, deg, h, agg, node_attr, pn, save=True):
         nd = spec.node
         nd.bind(pn)
         N, D = h.shape[0], nd.D
         out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
         ws = nd.workspace(h.device)
+        saved = nd.new_saved(N, h.device) if save else None
         check(native.lib().csmpn_egcl_node_forward(
             nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
             _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, out.data_ptr(),
-            ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
-        return out, ws
+            _ptr(saved), ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
+        return out, (ws, saved)
 
     @staticmethod
     def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None):
@@ -263,12 +277,12 @@ class HipBackend:
         gh = torch.empty_like(h)
         g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
         g_na = torch.empty_like(node_attr) if (node_attr is not None and want_gna) else None
-        ws = state if state is not None else nd.workspace(dev)
+        ws, saved = state if state is not None else (nd.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
         check(native.lib().csmpn_egcl_node_backward(
             nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
             _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, gout.data_ptr(),
-            gh.data_ptr(), g_agg.data_ptr(), _ptr(g_na), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
+            gh.data_ptr(), g_agg.data_ptr(), _ptr(g_na), _ptr(saved), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
         return gh, g_agg, g_na, views
 
     @staticmethod
@@ -279,12 +293,12 @@ class HipBackend:
         N, dev = h.shape[0], h.device
         _flat, views = e.new_grads(pe, dev)
         g_ea = torch.empty_like(edge_attr) if (edge_attr is not None and want_gea) else None
-        ws = state if state is not None else e.workspace(dev)
+        ws, saved = state if state is not None else (e.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
         check(native.lib().csmpn_egcl_edge_backward(
             e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
             csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(),
-            gh.data_ptr(), _ptr(g_ea), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
+            gh.data_ptr(), _ptr(g_ea), _ptr(saved), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
         return g_ea, views
 
 

@@ -152,7 +152,8 @@ struct Plan {
 
 // floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
 struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, off_idx, total; };
-TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen) {
+TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,
+                       bool use_saved = false) {
     int maxO = 0, maxCPo = 0;
     for (int k = 0; k < nblk; ++k) {
         maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
@@ -161,13 +162,15 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
     const int R = 16 * H, CS = R * D + 4, NW = 16 / H;
     const int MT = cdiv(maxO, NW);
     int sz_in = rup(blocks[0].in_features, 4) * CS;
-    if (bwd && R * blocks[0].in_features * D > sz_in) sz_in = rup(R * blocks[0].in_features * D, 4);  // gx staging
     const int sz_o = maxCPo * CS;
+    // backward with saved block inputs: ONE input buffer serves every block in turn
+    const bool single_in = bwd && use_saved && nblk > 1;
+    if (single_in && sz_o > sz_in) sz_in = sz_o;
     TileLayout L;
     int off = 0;
     L.off_in = off; off += sz_in;
-    L.off_p0 = off; off += (nblk >= 2) ? sz_o : 0;
-    L.off_p1 = off; off += (nblk >= 3) ? sz_o : 0;
+    L.off_p0 = off; off += (nblk >= 2 && !single_in) ? sz_o : 0;
+    L.off_p1 = off; off += (nblk >= 3 && !single_in) ? sz_o : 0;
     L.off_z = off; off += sz_o;
     L.off_g = off;
     int sz_g = bwd ? sz_o : 0;
@@ -231,10 +234,9 @@ int mirror_floats_of(int I, int O, int G, int P, bool sub) {
     return (sub ? G : 1) * O * I + 2 * G * O * O + 3 * O + 3 * O * G + O * P;
 }
 
-// H is a property of the CEMLP (not of the entry point): forward and backward of one layer
-// share the packed weights, so both must pick the same tile geometry. H = 2 (32-row tiles,
-// 8 lane columns per half) when every width is <= 8 channels, the algebra has the H = 2
-// kernels, and the backward layout still fits at least two row tiles beside the mirror.
+// Tile height per launch. H = 2 (32-row tiles, 8 lane columns per half) needs every width
+// <= 8 channels, an algebra with H = 2 kernels and the single-wave variant (which stages raw
+// weights in LDS, so no packed fragments are shared between launches of different H).
 int wstore_floats_of(int I, int O, int G, bool sub) {
     return (sub ? G : 1) * O * rup(I, 4) + 2 * G * O * rup(O, 4);
 }
@@ -252,25 +254,30 @@ int mirror_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
     return m;
 }
 
-int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
+int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,
+             bool use_saved, long rows) {
     int maxO = 0;
     for (int k = 0; k < nblk; ++k) maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
     if (maxO > 8 || !has_h2(id)) return 1;
     const int D = 1 << n, G = n + 1;
-    const TileLayout Lb = tile_layout(D, 2, blocks, nblk, true, 0);
-    const TileLayout Lf = tile_layout(D, 2, blocks, nblk, false, blocks[nblk - 1].out_features * D);
-    const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
+    const TileLayout L2 = tile_layout(D, 2, blocks, nblk, bwd, stage_rowlen, use_saved);
+    const size_t mirror = bwd ? (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4 : 0;
     const size_t wst = (size_t)wstore_total(G, blocks, nblk) * 4;
-    const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, wst, true);
-    const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, wst, false);
-    if (cb.var == VAR_WAVE && cb.rt * cb.wgs >= 2 && cf.var == VAR_WAVE && cf.rt * cf.wgs >= 2) return 2;
-    return 1;
+    const Choice c2 = choose_variant(1, (size_t)L2.total * 4, mirror, wst, bwd);
+    if (c2.var != VAR_WAVE || c2.rt * c2.wgs < 2) return 1;
+    // 32-row tiles only when there are enough of them to occupy every wave slot of the chip;
+    // small row counts (e.g. the node update of a 10k-node complex) get 16-row tiles
+    if (const char* f = getenv("CSMPN_FORCE_H")) return atoi(f) == 2 ? 2 : 1;   // debugging aid
+    const long tiles2 = (rows + 31) / 32;
+    if (tiles2 < 256L * c2.rt * c2.wgs) return 1;
+    return 2;
 }
 
 // bwd / stage_rowlen decide the footprint. stage_rowlen: dense staging row length needed in
 // buf_g (edge forward scatter).
 int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads, int nblk,
-              void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, Plan& plan) {
+              void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, bool use_saved, long rows,
+              Plan& plan) {
     if (nblk < 1 || nblk > CSMPN_MAX_BLOCKS) return fail(CSMPN_ERR_INVALID, "n_blocks=%d not in 1..%d", nblk, CSMPN_MAX_BLOCKS);
     const int D = 1 << n, G = n + 1, P = n_paths(id);
     memset(&plan, 0, sizeof(plan));
@@ -287,7 +294,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
             return fail(CSMPN_ERR_INVALID, "block %d: null parameter pointer", k);
         maxO = b.out_features > maxO ? b.out_features : maxO;
     }
-    const int H = decide_h(id, n, blocks, nblk);
+    const int H = decide_h(id, n, blocks, nblk, bwd, stage_rowlen, use_saved, rows);
     const int NW = 16 / H;
     const int MT = cdiv(maxO, NW);
     if (MT > 4) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 64 not supported", maxO);
@@ -346,7 +353,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     plan.pack_f4 = cursor;
 
     // buffers of one row tile (floats)
-    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen);
+    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved);
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
     C.off_red = L.off_red; C.off_idx = L.off_idx; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
@@ -532,6 +539,13 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
     return CSMPN_OK;
 }
 
+size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks) {
+    if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
+    size_t ch = 0;
+    for (int k = 0; k + 1 < n_blocks; ++k) ch += (size_t)blocks[k].out_features;
+    return ch << n;
+}
+
 size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks) {
     if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
     // H is not known without the metric: reserve for the larger packing (H = 2 when narrow)
@@ -559,35 +573,35 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,
-                        int64_t rows, float* y, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+                        int64_t rows, float* y, float* save_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
-    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan);
+    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, rows, plan);
     if (rc) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
-    io.y = y;
+    io.y = y; io.save = save_inputs;
     return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream);
 }
 
 int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
-                         int n_blocks, const float* x, const float* gy, int64_t rows, float* gx, void* workspace,
+                         int n_blocks, const float* x, const float* gy, int64_t rows, float* gx, const float* saved_inputs, void* workspace,
                          size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
-    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, rows, plan);
     if (rc) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
-    io.gy = gy; io.gx[0] = gx;
+    io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream);
 }
 
@@ -614,7 +628,7 @@ int csmpn_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* pe
 int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
                             int32_t channels, const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                             const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N, float* agg,
-                            void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+                            float* save_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
@@ -623,7 +637,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     const int D = 1 << n;
     Plan plan;
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false,
-                       blocks[n_blocks - 1].out_features * D, plan);
+                       blocks[n_blocks - 1].out_features * D, false, E, plan);
     if (rc) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
@@ -631,7 +645,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
     io.seg[0].a = h; io.seg[0].ia = dst_sorted; io.seg[0].b = h; io.seg[0].ib = src_sorted; io.seg[0].ch = channels;
     io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
-    io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
+    io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm; io.save = save_inputs;
     (void)N;
     return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream);
 }
@@ -640,7 +654,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
                              const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
                              const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                              const int32_t* src_sorted, const int32_t* dst_sorted, int64_t E, int64_t N,
-                             const float* g_agg, float* gh, float* g_edge_attr, void* workspace,
+                             const float* g_agg, float* gh, float* g_edge_attr, const float* saved_inputs, void* workspace,
                              size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
@@ -648,7 +662,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     if (channels + attr_channels != blocks[0].in_features)
         return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
     Plan plan;
-    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan);
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, E, plan);
     if (rc) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
@@ -657,7 +671,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     io.seg[0].a = h; io.seg[0].ia = dst_sorted; io.seg[0].b = h; io.seg[0].ib = src_sorted; io.seg[0].ch = channels;
     io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
     io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
-    io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr;
+    io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr; io.saved = saved_inputs;
     (void)N;
     return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream);
 }
@@ -684,7 +698,7 @@ static int node_io(const csmpn_block_params* blocks, int n_blocks, const float* 
 int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* h,
                             int32_t channels, const float* agg, int32_t agg_channels, const float* node_attr,
                             int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr, int32_t residual,
-                            int64_t N, float* out, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+                            int64_t N, float* out, float* save_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     RowIO io;
@@ -692,9 +706,9 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
                      residual, N, io);
     if (rc) return rc;
     Plan plan;
-    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, plan))) return rc;
+    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, N, plan))) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
-    io.y = out; io.resid = residual ? h : nullptr;
+    io.y = out; io.resid = residual ? h : nullptr; io.save = save_inputs;
     return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream);
 }
 
@@ -702,7 +716,7 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
                              const csmpn_block_grads* grads, int n_blocks, const float* h, int32_t channels,
                              const float* agg, int32_t agg_channels, const float* node_attr, int32_t attr_channels,
                              const int32_t* in_degree, int32_t mean_aggr, int32_t residual, int64_t N,
-                             const float* g_out, float* gh, float* g_agg, float* g_node_attr, void* workspace,
+                             const float* g_out, float* gh, float* g_agg, float* g_node_attr, const float* saved_inputs, void* workspace,
                              size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
@@ -711,10 +725,10 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
                      residual, N, io);
     if (rc) return rc;
     Plan plan;
-    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, plan))) return rc;
+    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, N, plan))) return rc;
     if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
-    io.resid_bwd = residual ? 1 : 0;
+    io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
     return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream);
 }
 

@@ -108,6 +108,10 @@ struct RowIO {
     float* gx[3];           // per segment gradient target (nullable)
     int resid_bwd;          // NODE: add gy to gx[0]
     int pad2_;
+    // inputs of blocks 1..nblk-1 ([rows, O_{k-1}, D] each, back to back): written by the
+    // forward when non-null, read by the backward instead of recomputing the earlier blocks
+    float* save;
+    const float* saved;
     unsigned long long* stamps;   // diagnostic (-DCSMPN_STAMPS) cycle accumulators, else null
 };
 

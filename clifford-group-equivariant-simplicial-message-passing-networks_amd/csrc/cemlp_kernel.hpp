@@ -10,16 +10,39 @@
 
 namespace csmpn {
 
+// The gathered row indices of one tile (3 x R ints in LDS): [0,R) first index array of
+// segment 0 (edge: dst), [R,2R) its second one (edge: src), [2R,3R) segment 1's (edge: perm);
+// -1 marks rows beyond the end. Loaded one tile AHEAD into registers (TileIdx) so that the
+// index -> row dependent load chain is off the critical path.
+struct TileIdx { int a, b, c; };
+
+template <int R>
+CSMPN_DEV TileIdx load_tile_indices(const RowIO& io, long row0, int tid) {
+    TileIdx t{-1, -1, -1};
+    const long grow = row0 + tid;
+    if (tid < R && grow < io.rows) {
+        const Seg& s0 = io.seg[0];
+        t.a = t.b = t.c = (int)grow;
+        if (s0.ia) t.a = s0.ia[grow];
+        if (s0.b && s0.ib) t.b = s0.ib[grow];
+        if (io.nseg > 1) { const int* ia1 = io.seg[1].ia; if (ia1) t.c = ia1[grow]; }
+    }
+    return t;
+}
+template <int R>
+CSMPN_DEV void store_tile_indices(const TileIdx& t, int* tidx, int tid) {
+    if (tid < R) { tidx[tid] = t.a; tidx[R + tid] = t.b; tidx[2 * R + tid] = t.c; }
+}
+
 // cooperative gather of the concatenated input rows of one tile into LDS [channel][D][R].
-// Thread mapping: consecutive threads take consecutive ROWS of one (channel, blade-quad),
-// so the LDS writes are conflict-free; the global reads are 16-byte pieces of R different
-// rows (the rows of a tile are L2-resident neighbours after the CSR sort).
+// Thread mapping: a thread keeps ONE row (consecutive threads = consecutive rows, so the LDS
+// writes are conflict-free) and walks over that row's 16-byte pieces.
 template <class ALG, int H>
-__device__ void stage_input(const RowIO& io, float* tile, int* tidx, int CP, long row0, int tid, int nthreads) {
+__device__ void stage_input(const RowIO& io, float* tile, const int* tidx, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
     constexpr int DQ = D / 4;   // float4 chunks per channel
-    // nthreads is a multiple of R: a thread keeps one row for the whole tile
+    // nthreads is a multiple of R
     const int row = tid % R, grp = tid / R, ngrp = nthreads / R;
     const long grow = row0 + row;
     const bool rvalid = grow < io.rows;
@@ -29,15 +52,12 @@ __device__ void stage_input(const RowIO& io, float* tile, int* tidx, int CP, lon
         long ra = 0, rb = 0;
         float scale = 1.0f;
         if (rvalid) {
-            ra = sg.ia ? (long)sg.ia[grow] : grow;
-            if (sg.b) rb = sg.ib ? (long)sg.ib[grow] : grow;
+            // the LDS index copies exist for the (at most three) index arrays of segments 0/1;
+            // segments without an index array are read by row number
+            ra = grow;
+            if (sg.ia) ra = s == 0 ? tidx[row] : tidx[2 * R + row];
+            if (sg.b) rb = sg.ib ? (long)tidx[R + row] : grow;
             if (sg.deg) { const int dg = sg.deg[ra]; scale = 1.0f / float(dg > 1 ? dg : 1); }
-        }
-        // keep the gathered row indices of this tile in LDS: the scatter / gradient gather of
-        // the same tile reuse them instead of issuing dependent global loads per row
-        if (grp == 0 && s < 2) {
-            if (s == 0) { tidx[row] = rvalid ? (int)ra : -1; tidx[R + row] = rvalid ? (int)rb : -1; }
-            else tidx[2 * R + row] = rvalid ? (int)ra : -1;
         }
         const float* pa = sg.a + ra * sg.ch * D;
         const float* pb = sg.b ? sg.b + rb * sg.ch * D : nullptr;
@@ -56,9 +76,32 @@ __device__ void stage_input(const RowIO& io, float* tile, int* tidx, int CP, lon
     }
     // zero the channel padding
     for (int e = tid; e < (CP - covered) * D * R; e += nthreads) {
-        const int row = e % R, rem = e / R;
+        const int row2 = e % R, rem = e / R;
         const int d = rem % D, pc = rem / D;
-        tile[(covered + pc) * CS + d * R + row] = 0.f;
+        tile[(covered + pc) * CS + d * R + row2] = 0.f;
+    }
+}
+
+// contiguous rows [rows][ch][D] (a saved block input) -> LDS tile [channel][D][R]
+template <class ALG, int H>
+__device__ void stage_plain(const float* src, int ch, long rows, float* tile, int CP, long row0, int tid, int nthreads) {
+    using GE = Geo<ALG, H>;
+    constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
+    constexpr int DQ = D / 4;
+    const int row = tid % R, grp = tid / R, ngrp = nthreads / R;
+    const long grow = row0 + row;
+    const bool rvalid = grow < rows;
+    const float* pa = src + grow * ch * D;
+    for (int rem = grp; rem < ch * DQ; rem += ngrp) {
+        const f4 v = rvalid ? *reinterpret_cast<const f4*>(pa + rem * 4) : splat(0.f);
+        const int dq = rem % DQ, c = rem / DQ;
+        float* p = tile + c * CS + (dq * 4) * R + row;
+        p[0] = v.x; p[R] = v.y; p[2 * R] = v.z; p[3 * R] = v.w;
+    }
+    for (int e = tid; e < (CP - ch) * D * R; e += nthreads) {
+        const int row2 = e % R, rem = e / R;
+        const int d = rem % D, pc = rem / D;
+        tile[(ch + pc) * CS + d * R + row2] = 0.f;
     }
 }
 
@@ -198,10 +241,28 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
     const long tiles_per_iter = (long)gridDim.x * RT;
     const long niter = (ntiles + tiles_per_iter - 1) / tiles_per_iter;
 
+    // element offset of block k's saved input (k >= 1) inside io.save / io.saved
+    auto save_off = [&](int kb) -> size_t {
+        size_t o = 0;
+        for (int j = 0; j + 1 < kb; ++j) o += (size_t)C.b[j].O;
+        return o * (size_t)io.rows * D;
+    };
+    const bool use_saved = BWD && io.saved != nullptr && C.nblk > 1;
+    TileIdx nidx = load_tile_indices<R>(io, ((long)blockIdx.x * RT + rt) * R, tid_rt);
+
     for (long iter = 0; iter < niter; ++iter) {
         const long tile = iter * tiles_per_iter + (long)blockIdx.x * RT + rt;
         const long row0 = tile * R;   // may be >= rows: fully masked tile
-        stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+        store_tile_indices<R>(nidx, tidx, tid_rt);
+        tile_sync<VAR>();
+        // the next tile's indices travel while this tile computes
+        nidx = load_tile_indices<R>(io, row0 + tiles_per_iter * R, tid_rt);
+        if (use_saved) {
+            const DevBlock& Bl = C.b[C.nblk - 1];
+            stage_plain<ALG, H>(io.saved + save_off(C.nblk - 1), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
+        } else {
+            stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+        }
         tile_sync<VAR>();
         ge.stamp(0);
 
@@ -217,6 +278,22 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR>();
                     store_tile<ALG, H>(out, buf_p(k), B.CPo, mt, ge);
+                    if (io.save) {   // keep the next block's input for the backward
+                        const int cs = NW * mt + ge.cn;
+                        if (cs < B.O) {
+                            float* sp = io.save + save_off(k + 1);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const long grow = row0 + ge.r0 + v;
+                                if (grow < io.rows) {
+#pragma unroll
+                                    for (int d4 = 0; d4 < D; d4 += 4)
+                                        *reinterpret_cast<f4*>(sp + (grow * B.O + cs) * D + d4) =
+                                            f4{out[d4][v], out[d4 + 1][v], out[d4 + 2][v], out[d4 + 3][v]};
+                                }
+                            }
+                        }
+                    }
                     tile_sync<VAR>();
                     in = buf_p(k);
                 }
@@ -271,9 +348,16 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
             ge.stamp(1);
             for (int k = C.nblk - 1; k >= 0; --k) {
                 const DevBlock& B = C.b[k];
-                // recompute the input tile of block k
                 const float* in = buf_in;
-                for (int j = 0; j < k; ++j) {
+                if (use_saved && k + 1 < C.nblk) {
+                    // this block's input replaces the previous one in the single input buffer
+                    if (k == 0) stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+                    else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
+                    tile_sync<VAR>();
+                    ge.stamp(2);
+                }
+                // without saved inputs: recompute the input tile of block k from the tile's input
+                for (int j = 0; !use_saved && j < k; ++j) {
                     const DevBlock& Bj = C.b[j];
                     const LaneParams<ALG> lpj = load_lane_params<ALG>(Bj, NW * mt + ge.cn);
                     FwdState<ALG> Sj;

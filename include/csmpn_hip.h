@@ -108,16 +108,24 @@ int csmpn_geometric_product_backward(const float* metric_host, int n, const floa
  * per-launch scratch for any entry point below that takes this CEMLP. */
 size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks);
 
+/* Saved block inputs (optional, every forward/backward pair below): the forward writes the
+ * inputs of blocks 1..n_blocks-1 ([rows, O_{k-1}, D] each, back to back; rows = rows / n_edges /
+ * n_nodes of the call, in the kernel's own row order) into save_inputs when it is non-NULL, and
+ * the backward reads them from saved_inputs instead of recomputing the earlier blocks (one
+ * block forward less per row, and a smaller LDS footprint). NULL on either side = recompute.
+ * Floats per row: csmpn_cemlp_saved_floats_per_row(). */
+size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks);
+
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
 int csmpn_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
-                        const float* x, int64_t rows, float* y, void* workspace, size_t workspace_bytes,
+                        const float* x, int64_t rows, float* y, float* save_inputs, void* workspace, size_t workspace_bytes,
                         uint32_t flags, void* stream);
 
 /* gx[rows, I_0, D] = d<gy,y>/dx (overwritten; may be NULL), grads += d/dparams.
  * Recomputes the forward in-kernel from x. */
 int csmpn_cemlp_backward(const float* metric_host, int n, const csmpn_block_params* blocks,
                          const csmpn_block_grads* grads, int n_blocks, const float* x, const float* gy,
-                         int64_t rows, float* gx, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+                         int64_t rows, float* gx, const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* One-time per complex: sort the E directed adjacencies by target.
  * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
@@ -137,7 +145,7 @@ int csmpn_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes,
 int csmpn_egcl_edge_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
                             const float* h, int32_t channels, const float* edge_attr, int32_t attr_channels,
                             const int32_t* perm, const int32_t* src_sorted, const int32_t* dst_sorted,
-                            int64_t n_edges, int64_t n_nodes, float* agg, void* workspace,
+                            int64_t n_edges, int64_t n_nodes, float* agg, float* save_inputs, void* workspace,
                             size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Backward of the above. g_agg [N,O,D] is d/d(agg) (already divided by the degree
@@ -148,7 +156,7 @@ int csmpn_egcl_edge_backward(const float* metric_host, int n, const csmpn_block_
                              const float* edge_attr, int32_t attr_channels, const int32_t* perm,
                              const int32_t* src_sorted, const int32_t* dst_sorted, int64_t n_edges,
                              int64_t n_nodes, const float* g_agg, float* gh, float* g_edge_attr,
-                             void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+                             const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* EGCL update (cegnn_utils.py:264-275):
  *   out[v] = (residual ? h[v] : 0) + NodeCEMLP(cat_c[h[v], agg[v] * s_v, node_attr[v]])
@@ -157,7 +165,7 @@ int csmpn_egcl_node_forward(const float* metric_host, int n, const csmpn_block_p
                             const float* h, int32_t channels, const float* agg, int32_t agg_channels,
                             const float* node_attr, int32_t attr_channels, const int32_t* in_degree,
                             int32_t mean_aggr, int32_t residual, int64_t n_nodes, float* out,
-                            void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+                            float* save_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Backward of the above: gh [N,C,D] (overwritten) = d/dh incl. residual,
  * g_agg [N,O,D] (overwritten) = d/d(agg) incl. the mean scale,
@@ -167,7 +175,7 @@ int csmpn_egcl_node_backward(const float* metric_host, int n, const csmpn_block_
                              const float* agg, int32_t agg_channels, const float* node_attr,
                              int32_t attr_channels, const int32_t* in_degree, int32_t mean_aggr,
                              int32_t residual, int64_t n_nodes, const float* g_out, float* gh, float* g_agg,
-                             float* g_node_attr, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+                             float* g_node_attr, const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Last error message of the calling thread (never NULL). */
 const char* csmpn_last_error(void);

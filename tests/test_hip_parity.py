@@ -245,7 +245,7 @@ def test_scatter_linearity_full_size(pkg):
         eas = ea[sel].contiguous()
         native.check(native.lib().csmpn_egcl_edge_forward(
             e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), C, eas.data_ptr(), 6, csr.perm.data_ptr(),
-            csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), ws.data_ptr(), ws.numel(), 0,
+            csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(), None, ws.data_ptr(), ws.numel(), 0,
             torch.cuda.current_stream().cuda_stream))
         return agg
     idx = torch.arange(E, device=dev())
@@ -297,3 +297,27 @@ def test_equivariance_rotation(pkg):
     y = layer(h.to(dev()), ei.to(dev()), ea.to(dev()), na.to(dev())).detach().cpu()
     yr = layer(rot(h).to(dev()), ei.to(dev()), rot(ea).to(dev()), rot(na).to(dev())).detach().cpu()
     assert relmax(yr.numpy(), rot(y).numpy()) < 2e-5
+
+
+def test_saved_inputs_vs_recompute(pkg):
+    """Backward from saved block inputs == backward that recomputes them (both C-ABI paths)."""
+    from csmpn_hip import ops
+    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+    torch.manual_seed(3)
+    layer = pkg.EGCL(alg, 8, 8, 8, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
+    h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), 700, 9000, 8, seed=7))
+    be, spec = ops.HipBackend, layer.spec()
+    csr = ops.get_csr(ei, 700)
+    pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+    gout = torch.randn(700, 8, 8, device=dev())
+    res = []
+    for save in (True, False):
+        agg, se = be.edge_forward(spec, csr, h, ea, pe, save=save)
+        out, sn = be.node_forward(spec, csr.deg, h, agg, na, pn, save=save)
+        assert (se[1] is not None) == save and (sn[1] is not None) == save
+        gh, g_agg, _, gn = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, sn)
+        _, ge = be.edge_backward(spec, csr, h, ea, pe, g_agg, gh, False, se)
+        torch.cuda.synchronize()
+        res.append([out, gh] + [g for g in ge + gn if g is not None])
+    for a, b in zip(*res):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
