@@ -237,13 +237,13 @@ int mirror_floats_of(int I, int O, int G, int P, bool sub) {
 // Tile height per launch. H = 2 (32-row tiles, 8 lane columns per half) needs every width
 // <= 8 channels, an algebra with H = 2 kernels and the single-wave variant (which stages raw
 // weights in LDS, so no packed fragments are shared between launches of different H).
-int wstore_floats_of(int I, int O, int G, bool sub) {
-    return (sub ? G : 1) * O * rup(I, 4) + 2 * G * O * rup(O, 4);
+int wstore_floats_of(int I, int O, int G, int P, bool sub) {
+    return (sub ? G : 1) * O * rup(I, 4) + 2 * G * O * rup(O, 4) + 3 * O + 3 * O * G + O * P;
 }
-int wstore_total(int G, const csmpn_block_params* blocks, int nblk) {
+int wstore_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
     int m = 0;
     for (int k = 0; k < nblk; ++k)
-        m += rup(wstore_floats_of(blocks[k].in_features, blocks[k].out_features, G, blocks[k].lin_subspaces != 0), 4);
+        m += rup(wstore_floats_of(blocks[k].in_features, blocks[k].out_features, G, P, blocks[k].lin_subspaces != 0), 4);
     return m;
 }
 
@@ -262,7 +262,7 @@ int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool b
     const int D = 1 << n, G = n + 1;
     const TileLayout L2 = tile_layout(D, 2, blocks, nblk, bwd, stage_rowlen, use_saved);
     const size_t mirror = bwd ? (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4 : 0;
-    const size_t wst = (size_t)wstore_total(G, blocks, nblk) * 4;
+    const size_t wst = (size_t)wstore_total(G, n_paths(id), blocks, nblk) * 4;
     const Choice c2 = choose_variant(1, (size_t)L2.total * 4, mirror, wst, bwd);
     if (c2.var != VAR_WAVE || c2.rt * c2.wgs < 2) return 1;
     // 32-row tiles only when there are enough of them to occupy every wave slot of the chip;
@@ -338,7 +338,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         B.W1 = b.lin_w; B.WR = b.right_w; B.WL = b.left_w;
         B.lds_goff = mirror;
         B.lds_woff = wstore;
-        wstore += rup(wstore_floats_of(B.I, B.O, G, B.w1_sub != 0), 4);
+        wstore += rup(wstore_floats_of(B.I, B.O, G, P, B.w1_sub != 0), 4);
         mirror += rup(mirror_floats_of(B.I, B.O, G, P, B.w1_sub), 4);
         if (bwd) {
             if (!grads) return fail(CSMPN_ERR_INVALID, "grads is null");

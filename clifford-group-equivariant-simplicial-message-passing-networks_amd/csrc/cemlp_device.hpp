@@ -260,13 +260,23 @@ CSMPN_DEV void tile_sync() {
 // channels padded to 4 (padding zero-filled), so that a forward B fragment is ONE
 // ds_read_b128 and a transposed one four ds_read_b32 - no pre-packed, per-lane duplicated
 // fragments and no global-memory latency in front of the MFMAs.
-struct WOff { int W1, WR, WL, total; };
-CSMPN_DEV WOff wstore_offsets(int O, int CPi, int CPo, int G, bool w1_sub) {
+// ... followed by the per-channel parameters (b1, silu a/b, sigmoid(norm a), left bias, layer
+// norm a, path weights), so that a tile reads ALL its parameters from LDS.
+struct WOff { int W1, WR, WL, b1, sa, sb, sg, bL, la, w, total; };
+CSMPN_DEV WOff wstore_offsets(int O, int CPi, int CPo, int G, int P, bool w1_sub) {
     WOff w;
-    w.W1 = 0;
-    w.WR = (w1_sub ? G : 1) * O * CPi;
-    w.WL = w.WR + G * O * CPo;
-    w.total = w.WL + G * O * CPo;
+    int o = 0;
+    w.W1 = o; o += (w1_sub ? G : 1) * O * CPi;
+    w.WR = o; o += G * O * CPo;
+    w.WL = o; o += G * O * CPo;
+    w.b1 = o; o += O;
+    w.sa = o; o += O * G;
+    w.sb = o; o += O * G;
+    w.sg = o; o += O * G;
+    w.bL = o; o += O;
+    w.la = o; o += O;
+    w.w = o; o += O * P;
+    w.total = o;
     return w;
 }
 
@@ -364,26 +374,28 @@ CSMPN_DEV void weight_grad(const f4 (&gr)[ALG::D], const float* tile, int CP, in
             }
             accg[g] = acc;
         });
-        if (cin < I && hi == ge.h) {
+        // one predicate for the whole store: lanes outside the tile skip it, inside it every
+        // (o, cin) pair is owned by exactly this lane (plus its twin in the other row half)
+        if (cin < I && hi == ge.h && ob < O) {
+            const bool full = ob + 3 < O;
             if (has_grades) {
                 static_for<0, G>([&](auto g) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int o = ob + v;
-                        if (o < O) {
-                            float* p = MIRROR ? dstp + (g * O + o) * I + cin : dstp + (o * I + cin) * G + g;
-                            atomicAdd(p, accg[g][v]);
-                        }
+                    float* p = MIRROR ? dstp + (g * O + ob) * I + cin : dstp + (ob * I + cin) * G + g;
+                    const int so = MIRROR ? I : I * G;   // stride between consecutive out channels
+                    atomicAdd(p, accg[g][0]);
+                    if (full) {
+                        atomicAdd(p + so, accg[g][1]); atomicAdd(p + 2 * so, accg[g][2]); atomicAdd(p + 3 * so, accg[g][3]);
+                    } else {
+                        if (ob + 1 < O) atomicAdd(p + so, accg[g][1]);
+                        if (ob + 2 < O) atomicAdd(p + 2 * so, accg[g][2]);
                     }
                 });
             } else {
                 f4 tot = accg[0];
                 static_for<1, G>([&](auto g) { tot += accg[g]; });
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int o = ob + v;
-                    if (o < O) atomicAdd(dstp + o * I + cin, tot[v]);
-                }
+                for (int v = 0; v < 4; ++v)
+                    if (ob + v < O) atomicAdd(dstp + (ob + v) * I + cin, tot[v]);
             }
         }
     }
@@ -425,6 +437,26 @@ CSMPN_DEV LaneParams<ALG> load_lane_params(const DevBlock& B, int c) {
         p.sa[g] = p.cvalid ? B.sa[cc * G + g] : 0.f;
         p.sb[g] = p.cvalid ? B.sb[cc * G + g] : 0.f;
         p.sg[g] = p.cvalid ? sigmoidf(B.an[cc * G + g]) : 0.f;
+    }
+    return p;
+}
+
+// same, from the LDS parameter store (VAR_WAVE): no global-memory latency per tile
+template <class ALG>
+CSMPN_DEV LaneParams<ALG> load_lane_params_lds(const DevBlock& B, const float* ws, const WOff& wo, int c) {
+    constexpr int G = ALG::G;
+    LaneParams<ALG> p;
+    p.cvalid = c < B.O;
+    const int cc = p.cvalid ? c : 0;
+    const float m = p.cvalid ? 1.0f : 0.0f;
+    p.b1 = ws[wo.b1 + cc] * m;
+    p.bL = ws[wo.bL + cc] * m;
+    p.la = ws[wo.la + cc] * m;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        p.sa[g] = ws[wo.sa + cc * G + g] * m;
+        p.sb[g] = ws[wo.sb + cc * G + g] * m;
+        p.sg[g] = ws[wo.sg + cc * G + g] * m;
     }
     return p;
 }
@@ -541,7 +573,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     const int c = NW * mt + ge.cn;
     const bool tile_active = NW * mt < B.O;
     constexpr bool WLDS = VAR == VAR_WAVE;
-    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
     const WSrc sW1{B.pfW1, wstore + B.lds_woff + wo.W1, B.O, B.CPi, B.w1_sub};
     const WSrc sWR{B.pfWR, wstore + B.lds_woff + wo.WR, B.O, B.CPo, 1};
     const WSrc sWL{B.pfWL, wstore + B.lds_woff + wo.WL, B.O, B.CPo, 1};
@@ -607,7 +639,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     ge.stamp(6);
     CSMPN_PHASE();
     // 5. steerable geometric product + first-order term (cegnn_utils.py:126-152)
-    if (lp.cvalid) weighted_gp<ALG>(L, z, r, B.w + (size_t)c * ALG::P);
+    if (lp.cvalid) weighted_gp<ALG>(L, z, r, (WLDS ? wstore + B.lds_woff + wo.w : B.w) + (size_t)c * ALG::P);
 #pragma unroll
     for (int d = 0; d < D; ++d) S.s[d] = L[d] * kInvSqrt2;
 
@@ -651,7 +683,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     const bool cv = lp.cvalid;
     const int cc = cv ? c : 0;
     constexpr bool WLDS = VAR == VAR_WAVE;
-    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+    const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
     const WSrc sWRt{B.pbWR, wstore + B.lds_woff + wo.WR, B.O, B.CPo, 1};
     const WSrc sWLt{B.pbWL, wstore + B.lds_woff + wo.WL, B.O, B.CPo, 1};
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, P, B.w1_sub != 0);
@@ -716,7 +748,9 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     for (int d = 0; d < D; ++d) gr[d] = splat(0.f);
 #pragma unroll
     for (int p = 0; p < P; ++p) p_w[p] = 0.f;
-    if (tile_active) weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, B.w + (size_t)cc * P, gz, gr, p_w);
+    if (tile_active)
+        weighted_gp_bwd<ALG>(ggp, S.y, S.gate, S.R, S.invden, (WLDS ? wstore + B.lds_woff + wo.w : B.w) + (size_t)cc * P,
+                             gz, gr, p_w);
 
     ge.stamp(11);
     CSMPN_PHASE();
@@ -813,6 +847,7 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         }
     }
 
+    ge.stamp(15);
     // ---- MVLinear weight gradient; gy tile to LDS for the transposed MVLinear
     tile_sync<VAR>();   // all reads of gbuf (GR) done
     store_tile<ALG, H>(gy, gbuf, B.CPo, mt, ge);

@@ -226,15 +226,34 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
     if constexpr (WLDS) {
         for (int k = 0; k < C.nblk; ++k) {
             const DevBlock& B = C.b[k];
-            const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+            const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
             float* ws = wstore + B.lds_woff;
             stage_weight(B.W1, ws + wo.W1, B.O, B.I, B.CPi, G, B.w1_sub != 0, threadIdx.x, blockDim.x);
             stage_weight(B.WR, ws + wo.WR, B.O, B.O, B.CPo, G, true, threadIdx.x, blockDim.x);
             stage_weight(B.WL, ws + wo.WL, B.O, B.O, B.CPo, G, true, threadIdx.x, blockDim.x);
+            for (int e = threadIdx.x; e < B.O; e += blockDim.x) {
+                ws[wo.b1 + e] = B.has_b1 ? B.b1[e] : 0.f;
+                ws[wo.bL + e] = B.bL[e];
+                ws[wo.la + e] = B.la[e];
+            }
+            for (int e = threadIdx.x; e < B.O * G; e += blockDim.x) {
+                ws[wo.sa + e] = B.sa[e];
+                ws[wo.sb + e] = B.sb[e];
+                ws[wo.sg + e] = sigmoidf(B.an[e]);
+            }
+            for (int e = threadIdx.x; e < B.O * ALG::P; e += blockDim.x) ws[wo.w + e] = B.w[e];
         }
         __syncthreads();
     }
 
+    auto lane_params = [&](const DevBlock& B, int c) -> LaneParams<ALG> {
+        if constexpr (WLDS) {
+            const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
+            return load_lane_params_lds<ALG>(B, wstore + B.lds_woff, wo, c);
+        } else {
+            return load_lane_params<ALG>(B, c);
+        }
+    };
     const DevBlock& B0 = C.b[0];
     const DevBlock& BL = C.b[C.nblk - 1];
     const long ntiles = (io.rows + R - 1) / R;
@@ -272,7 +291,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
             f4 out[D];
             for (int k = 0; k < C.nblk; ++k) {
                 const DevBlock& B = C.b[k];
-                const LaneParams<ALG> lp = load_lane_params<ALG>(B, NW * mt + ge.cn);
+                const LaneParams<ALG> lp = lane_params(B, NW * mt + ge.cn);
                 FwdState<ALG> S;
                 block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, out);
                 if (k + 1 < C.nblk) {
@@ -359,7 +378,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 // without saved inputs: recompute the input tile of block k from the tile's input
                 for (int j = 0; !use_saved && j < k; ++j) {
                     const DevBlock& Bj = C.b[j];
-                    const LaneParams<ALG> lpj = load_lane_params<ALG>(Bj, NW * mt + ge.cn);
+                    const LaneParams<ALG> lpj = lane_params(Bj, NW * mt + ge.cn);
                     FwdState<ALG> Sj;
                     f4 oj[D];
                     block_forward<ALG, H, VAR>(Bj, lpj, in, buf_z, red, wstore, MT, mt, ge, Sj, oj);
@@ -369,7 +388,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     ge.stamp(2);
                     in = buf_p(j);
                 }
-                const LaneParams<ALG> lp = load_lane_params<ALG>(B, NW * mt + ge.cn);
+                const LaneParams<ALG> lp = lane_params(B, NW * mt + ge.cn);
                 f4 gy[D];
                 {
                     FwdState<ALG> S;
@@ -378,7 +397,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy);
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
-                const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, B.w1_sub != 0);
+                const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
                 const WSrc sW1t{B.pbW1, wstore + B.lds_woff + wo.W1, B.O, B.CPi, B.w1_sub};
                 if (k > 0) {
 #pragma unroll
