@@ -168,14 +168,26 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
     if (single_in && sz_o > sz_in) sz_in = sz_o;
     TileLayout L;
     int off = 0;
-    L.off_in = off; off += sz_in;
-    L.off_p0 = off; off += (nblk >= 2 && !single_in) ? sz_o : 0;
-    L.off_p1 = off; off += (nblk >= 3 && !single_in) ? sz_o : 0;
-    L.off_z = off; off += sz_o;
-    L.off_g = off;
-    int sz_g = bwd ? sz_o : 0;
-    if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
-    off += sz_g;
+    if (!bwd) {
+        // forward: a block reads its input tile only in its first phase (MVLinear) and writes
+        // its output after its last one, so the output of block k may overwrite the input of
+        // block k (ping-pong degenerates to ONE input buffer); the dense scatter staging of
+        // the edge forward reuses the z buffer, dead by then.
+        const int sz_io = (nblk >= 2 && sz_o > sz_in) ? sz_o : sz_in;
+        L.off_in = off; L.off_p0 = off; L.off_p1 = off; off += sz_io;
+        int sz_z = sz_o;
+        if (stage_rowlen > 0 && R * stage_rowlen > sz_z) sz_z = rup(R * stage_rowlen, 4);
+        L.off_z = off; L.off_g = off; off += sz_z;
+    } else {
+        L.off_in = off; off += sz_in;
+        L.off_p0 = off; off += (nblk >= 2 && !single_in) ? sz_o : 0;
+        L.off_p1 = off; off += (nblk >= 3 && !single_in) ? sz_o : 0;
+        L.off_z = off; off += sz_o;
+        L.off_g = off;
+        int sz_g = sz_o;
+        if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
+        off += sz_g;
+    }
     L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
     L.off_idx = off; off += rup(3 * R, 4);   // int copies of the tile's gathered row indices
     L.total = off;
