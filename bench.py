@@ -52,6 +52,24 @@ def algorithmic_bytes(C, D, A=6, T=3):
     }
 
 
+def pmc_traffic(stage):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
+    same workload (separate --pmc passes, tools/profile_r01.sh): 2 x FETCH_SIZE (gfx950 counts a
+    wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> B.
+    None when no summary is committed (counters cannot be read from inside the timed run)."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_summary.json")
+    tag = {"edge_fwd": "1, 0, 2, false", "edge_bwd": "1, 0, 2, true", "node_fwd": "2, 0, 1, false",
+           "node_bwd": "2, 0, 1, true"}.get(stage)
+    try:
+        with open(path) as f:
+            for name, c in json.load(f).items():
+                if tag and f"Alg<3, 0u>, {tag}>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    except OSError:
+        pass
+    return None
+
+
 def make_inputs(metric, C, N, E_total, lo, hi, device):
     """Seeded S-series generator; returns this rank's shard [lo, hi)."""
     D = 1 << len(metric)
@@ -233,7 +251,7 @@ def main():
         bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
         roofline = {
             "bound": "hbm", "kernel": f"cemlp_kernel<{dom}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "layer_bytes_per_edge": round(bytes_per_edge, 1),
