@@ -245,11 +245,12 @@ CSMPN_DEV void tile_sync() {
     if constexpr (kVarBarrier<VAR>) {
         __syncthreads();
     } else {
-        // one wave owns the tile: LDS operations of a wave execute in order, only
-        // the compiler must not move them across this point
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // one wave owns the tile: the LDS executes a wave's operations in issue order, so no
+        // hardware wait is needed - only the compiler must not move LDS accesses across this
+        // point (a wavefront-scope fence would also drain outstanding global loads/atomics).
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        asm volatile("" ::: "memory");
     }
 }
 
