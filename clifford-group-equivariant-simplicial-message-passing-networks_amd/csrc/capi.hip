@@ -174,10 +174,18 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
         // block k (ping-pong degenerates to ONE input buffer); the dense scatter staging of
         // the edge forward reuses the z buffer, dead by then.
         const int sz_io = (nblk >= 2 && sz_o > sz_in) ? sz_o : sz_in;
-        L.off_in = off; L.off_p0 = off; L.off_p1 = off; off += sz_io;
         int sz_z = sz_o;
         if (stage_rowlen > 0 && R * stage_rowlen > sz_z) sz_z = rup(R * stage_rowlen, 4);
-        L.off_z = off; L.off_g = off; off += sz_z;
+        if (MT == 1) {
+            // single-wave tiles: the gated activations z are written after the block's only
+            // read of its input (MVLinear) and the LDS executes a wave in order, so z (and the
+            // scatter staging) share the input buffer too: ONE buffer per tile.
+            const int sz_all = sz_io > sz_z ? sz_io : sz_z;
+            L.off_in = off; L.off_p0 = off; L.off_p1 = off; L.off_z = off; L.off_g = off; off += sz_all;
+        } else {
+            L.off_in = off; L.off_p0 = off; L.off_p1 = off; off += sz_io;
+            L.off_z = off; L.off_g = off; off += sz_z;
+        }
     } else {
         L.off_in = off; off += sz_in;
         L.off_p0 = off; off += (nblk >= 2 && !single_in) ? sz_o : 0;

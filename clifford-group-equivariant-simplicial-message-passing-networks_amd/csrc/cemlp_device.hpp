@@ -605,6 +605,9 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 #pragma unroll
         for (int t = 0; t < nd; ++t) z[d0 + t] = S.gate[g] * S.y[d0 + t];
     });
+    // single-wave forward tiles keep z in the buffer the MVLinear just read (host layout):
+    // nothing may move the stores above those reads
+    if constexpr (VAR == VAR_WAVE) tile_sync<VAR>();
     store_tile<ALG, H>(z, zbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
     ge.stamp(4);

@@ -35,42 +35,55 @@ CSMPN_DEV void store_tile_indices(const TileIdx& t, int* tidx, int tid) {
 }
 
 // cooperative gather of the concatenated input rows of one tile into LDS [channel][D][R].
-// Thread mapping: a thread keeps ONE row (consecutive threads = consecutive rows, so the LDS
-// writes are conflict-free) and walks over that row's 16-byte pieces.
+// Thread mapping: consecutive threads take consecutive 16-byte pieces of ONE row, so a load
+// instruction covers whole rows (256-byte rows: 4 rows = 8 cache lines per wave instruction).
+// A row-per-lane mapping touches 32-64 different lines per instruction and is bound by the
+// address unit (measured: 39 % of the edge forward). The transposing LDS writes are at most
+// 2-way bank conflicts, free for ds_write_b32.
 template <class ALG, int H>
 __device__ void stage_input(const RowIO& io, float* tile, const int* tidx, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
-    constexpr int DQ = D / 4;   // float4 chunks per channel
-    // nthreads is a multiple of R
-    const int row = tid % R, grp = tid / R, ngrp = nthreads / R;
-    const long grow = row0 + row;
-    const bool rvalid = grow < io.rows;
+    constexpr int DQ = D / 4;   // float4 pieces per channel (power of two)
     int covered = 0;
     for (int s = 0; s < io.nseg; ++s) {
         const Seg& sg = io.seg[s];
-        long ra = 0, rb = 0;
-        float scale = 1.0f;
-        if (rvalid) {
-            // the LDS index copies exist for the (at most three) index arrays of segments 0/1;
-            // segments without an index array are read by row number
-            ra = grow;
-            if (sg.ia) ra = s == 0 ? tidx[row] : tidx[2 * R + row];
-            if (sg.b) rb = sg.ib ? (long)tidx[R + row] : grow;
-            if (sg.deg) { const int dg = sg.deg[ra]; scale = 1.0f / float(dg > 1 ? dg : 1); }
-        }
-        const float* pa = sg.a + ra * sg.ch * D;
-        const float* pb = sg.b ? sg.b + rb * sg.ch * D : nullptr;
-        for (int rem = grp; rem < sg.ch * DQ; rem += ngrp) {
-            f4 v = splat(0.f);
-            if (rvalid) {
-                v = *reinterpret_cast<const f4*>(pa + rem * 4);
-                if (pb) v -= *reinterpret_cast<const f4*>(pb + rem * 4);
-                v *= scale;
+        const int ppr = sg.ch * DQ;            // pieces per row
+        const float inv = 1.0f / float(ppr);
+        const int* ta = s == 0 ? tidx : tidx + 2 * R;
+        // batches of U pieces per thread: all loads of a batch are in flight before the first
+        // one is consumed (a plain loop serialises one memory round trip per iteration)
+        constexpr int U = 4;
+        for (int e0 = tid; e0 < R * ppr; e0 += U * nthreads) {
+            f4 v[U];
+            int row[U], p[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * nthreads;
+                row[u] = (int)((float(e) + 0.5f) * inv);   // exact: e < 2^20
+                p[u] = e - row[u] * ppr;
+                const long grow = row0 + row[u];
+                v[u] = splat(0.f);
+                if (e < R * ppr && grow < io.rows) {
+                    // the LDS index copies exist for the (at most three) index arrays of
+                    // segments 0/1; segments without an index array are read by row number
+                    const long ra = sg.ia ? (long)ta[row[u]] : grow;
+                    v[u] = *reinterpret_cast<const f4*>(sg.a + (ra * ppr + p[u]) * 4);
+                    if (sg.b) {
+                        const long rb = sg.ib ? (long)tidx[R + row[u]] : grow;
+                        v[u] -= *reinterpret_cast<const f4*>(sg.b + (rb * ppr + p[u]) * 4);
+                    }
+                    if (sg.deg) { const int dg = sg.deg[ra]; v[u] *= 1.0f / float(dg > 1 ? dg : 1); }
+                }
             }
-            const int dq = rem % DQ, ch = rem / DQ;
-            float* p = tile + (sg.off + ch) * CS + (dq * 4) * R + row;
-            p[0] = v.x; p[R] = v.y; p[2 * R] = v.z; p[3 * R] = v.w;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e0 + u * nthreads < R * ppr) {
+                    const int dq = p[u] % DQ, ch = p[u] / DQ;
+                    float* q = tile + (sg.off + ch) * CS + (dq * 4) * R + row[u];
+                    q[0] = v[u].x; q[R] = v[u].y; q[2 * R] = v[u].z; q[3 * R] = v[u].w;
+                }
+            }
         }
         covered = sg.off + sg.ch;
     }
@@ -82,21 +95,36 @@ __device__ void stage_input(const RowIO& io, float* tile, const int* tidx, int C
     }
 }
 
-// contiguous rows [rows][ch][D] (a saved block input) -> LDS tile [channel][D][R]
+// contiguous rows [rows][ch][D] (a saved block input) -> LDS tile [channel][D][R]; a tile's
+// rows are one contiguous span, read fully coalesced
 template <class ALG, int H>
 __device__ void stage_plain(const float* src, int ch, long rows, float* tile, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
     constexpr int DQ = D / 4;
-    const int row = tid % R, grp = tid / R, ngrp = nthreads / R;
-    const long grow = row0 + row;
-    const bool rvalid = grow < rows;
-    const float* pa = src + grow * ch * D;
-    for (int rem = grp; rem < ch * DQ; rem += ngrp) {
-        const f4 v = rvalid ? *reinterpret_cast<const f4*>(pa + rem * 4) : splat(0.f);
-        const int dq = rem % DQ, c = rem / DQ;
-        float* p = tile + c * CS + (dq * 4) * R + row;
-        p[0] = v.x; p[R] = v.y; p[2 * R] = v.z; p[3 * R] = v.w;
+    const int ppr = ch * DQ;
+    const float inv = 1.0f / float(ppr);
+    const float* base = src + row0 * ppr * 4;
+    constexpr int U = 4;
+    for (int e0 = tid; e0 < R * ppr; e0 += U * nthreads) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * nthreads;
+            const int row = (int)((float(e) + 0.5f) * inv);
+            v[u] = (e < R * ppr && row0 + row < rows) ? *reinterpret_cast<const f4*>(base + (size_t)e * 4) : splat(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * nthreads;
+            if (e < R * ppr) {
+                const int row = (int)((float(e) + 0.5f) * inv);
+                const int p = e - row * ppr;
+                const int dq = p % DQ, c = p / DQ;
+                float* q = tile + c * CS + (dq * 4) * R + row;
+                q[0] = v[u].x; q[R] = v[u].y; q[2 * R] = v[u].z; q[3 * R] = v[u].w;
+            }
+        }
     }
     for (int e = tid; e < (CP - ch) * D * R; e += nthreads) {
         const int row2 = e % R, rem = e / R;
