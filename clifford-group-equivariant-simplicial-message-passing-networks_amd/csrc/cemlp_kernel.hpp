@@ -438,6 +438,14 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
                     const int Cs0 = io.seg[0].ch;
                     for (int it = mt; it < B.NTi; it += MT) {
+                        // skip input-channel tiles none of whose segments wants a gradient
+                        // (attributes without grad): uniform per wave
+                        bool wanted = false;
+                        for (int t = 0; t < io.nseg; ++t) {
+                            const bool overlaps = io.seg[t].off < NW * (it + 1) && io.seg[t].off + io.seg[t].ch > NW * it;
+                            wanted |= overlaps && ((MODE == MODE_EDGE && t == 0) || io.gx[t] != nullptr);
+                        }
+                        if (!wanted) continue;
                         f4 gx[D];
 #pragma unroll
                         for (int d = 0; d < D; ++d) gx[d] = splat(0.f);
