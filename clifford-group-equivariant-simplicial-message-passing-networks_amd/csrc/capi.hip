@@ -194,6 +194,7 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
         L.off_g = off;
         int sz_g = sz_o;
         if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
+        if (MT == 1 && 256 * D > sz_g) sz_g = 256 * D;   // parking area of the incoming gradient
         off += sz_g;
     }
     L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;

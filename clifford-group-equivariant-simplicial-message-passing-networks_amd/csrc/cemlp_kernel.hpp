@@ -209,6 +209,20 @@ __device__ inline void stage_weight(const float* w, float* dst, int O, int I, in
     }
 }
 
+// park / fetch a lane-layout tensor in a wave-private LDS area (one b128 per blade per lane,
+// conflict-free): used to keep the incoming gradient out of the registers while a block's
+// forward is recomputed
+template <class ALG>
+CSMPN_DEV void park(const f4 (&t)[ALG::D], float* area, int lane) {
+#pragma unroll
+    for (int d = 0; d < ALG::D; ++d) *reinterpret_cast<f4*>(area + (d * 64 + lane) * 4) = t[d];
+}
+template <class ALG>
+CSMPN_DEV void unpark(f4 (&t)[ALG::D], const float* area, int lane) {
+#pragma unroll
+    for (int d = 0; d < ALG::D; ++d) t[d] = *reinterpret_cast<const f4*>(area + (d * 64 + lane) * 4);
+}
+
 // Forward: 512 threads (2 waves/SIMD at <=256 VGPRs). Backward keeps the whole forward
 // state of a block live: 256 threads (1 wave/SIMD, up to 512 VGPRs).
 template <class ALG, int MODE, int VAR, int H, bool BWD>
@@ -392,6 +406,10 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     }
                 }
             }
+            // single-wave tiles: the incoming gradient waits in the (still unused) g buffer
+            // while the block forward is recomputed, instead of occupying 4*D VGPRs
+            constexpr bool PARK = VAR == VAR_WAVE;
+            if constexpr (PARK) park<ALG>(gout, buf_g, lane);
             ge.stamp(1);
             for (int k = C.nblk - 1; k >= 0; --k) {
                 const DevBlock& B = C.b[k];
@@ -422,6 +440,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     FwdState<ALG> S;
                     f4 unused[D];
                     block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused);
+                    if constexpr (PARK) { tile_sync<VAR>(); unpark<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
                     block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy);
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
@@ -433,6 +452,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     if (mt < B.NTi)
                         linear_from_tile<ALG, H, WLDS, true>(gout, buf_g, B.CPo, B.KKo, sW1t, mt, ge);
                     tile_sync<VAR>();
+                    if constexpr (PARK) { park<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
                     ge.stamp(17);
                 } else {
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
