@@ -69,6 +69,25 @@ bool has_h2(AlgId id) {
     }
 }
 
+bool has_ps(AlgId id) {
+    switch (id) {
+        case ALG_N3: return has_ps_n3();
+        case ALG_N5: return has_ps_n5();
+        case ALG_N5M: return has_ps_n5m();
+        default: return false;
+    }
+}
+
+hipError_t launch_cemlp_ps(AlgId id, int mode, bool bwd, unsigned grid, unsigned block, size_t lds, hipStream_t st,
+                           const DevCemlp& C, const RowIO& io) {
+    switch (id) {
+        case ALG_N3: return launch_cemlp_ps_n3(mode, bwd, grid, block, lds, st, C, io);
+        case ALG_N5: return launch_cemlp_ps_n5(mode, bwd, grid, block, lds, st, C, io);
+        case ALG_N5M: return launch_cemlp_ps_n5m(mode, bwd, grid, block, lds, st, C, io);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 int n_paths(AlgId id) {
     switch (id) {
         case ALG_N2: return Alg<2, 0u>::P;
@@ -148,12 +167,13 @@ struct Plan {
     unsigned grid_cap;    // workgroups that fit on the chip at once
     int var;              // VAR_WAVE / VAR_GROUP / VAR_GROUP_NM / VAR_GLOBAL
     int H;                // row halves per tile
+    bool ps;              // parity-split kernels (cemlp_ps.hpp): 16-row tiles, 8 channels x 2 blade parities
 };
 
 // floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
 struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, off_idx, total; };
 TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,
-                       bool use_saved = false) {
+                       bool use_saved = false, bool ps = false) {
     int maxO = 0, maxCPo = 0;
     for (int k = 0; k < nblk; ++k) {
         maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
@@ -194,7 +214,8 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
         L.off_g = off;
         int sz_g = sz_o;
         if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
-        if (MT == 1 && 256 * D > sz_g) sz_g = 256 * D;   // parking area of the incoming gradient
+        const int park = ps ? 128 * D : 256 * D;         // parking area of the incoming gradient
+        if (MT == 1 && park > sz_g) sz_g = park;
         off += sz_g;
     }
     L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
@@ -204,11 +225,15 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
 }
 struct Choice { int var, rt, wgs; bool mirror; };
 // backward kernels are built for 256 threads (512 VGPRs), forward for 512 threads
-Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wstore_bytes, bool bwd) {
-    const int max_rt = ((bwd ? 4 : 8) / MT) > 0 ? (bwd ? 4 : 8) / MT : 1;
+Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wstore_bytes, bool bwd, bool ps = false) {
+    // workgroups of at most 512 threads (forward, parity-split backward) / 256 threads (backward)
+    // parity-split forward: 256-thread workgroups, three per CU (168 VGPRs: 3 waves per SIMD)
+    const int waves = ps ? (bwd ? 8 : 4) : (bwd ? 4 : 8);
+    const int max_wgs = (ps && !bwd) ? 3 : 2;
+    const int max_rt = (waves / MT) > 0 ? waves / MT : 1;
     auto fit = [&](size_t fixed, int& rt_out, int& wgs_out) {
         int best_waves = 0;
-        for (int wgs = 1; wgs <= 2; ++wgs) {
+        for (int wgs = 1; wgs <= max_wgs; ++wgs) {
             const size_t budget = (size_t)kMaxLdsBytes / wgs;
             if (budget <= fixed) continue;
             int rt = (int)((budget - fixed) / tile_bytes);
@@ -275,6 +300,27 @@ int mirror_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
     return m;
 }
 
+// Parity-split kernels: odd n, every block at most 8 output channels, tiles + weight store +
+// gradient mirror resident in LDS. The decision does not depend on the direction or the row
+// count, so a forward and the backward that reads its saved block inputs always agree.
+bool decide_ps(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
+    if (!has_ps(id)) return false;
+    // Opt-in (CSMPN_FORCE_PS=1): measured 15-20 % slower than the 32-row layout on S1 despite
+    // twice the resident waves (negative results).
+    const char* f = getenv("CSMPN_FORCE_PS");
+    if (!f || atoi(f) == 0) return false;
+    for (int k = 0; k < nblk; ++k) if (blocks[k].out_features > 8) return false;
+    const int D = 1 << n, G = n + 1;
+    const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
+    const size_t wst = (size_t)wstore_total(G, n_paths(id), blocks, nblk) * 4;
+    // worst case: backward without saved inputs, forward with the widest staging row
+    const TileLayout Lb = tile_layout(D, 1, blocks, nblk, true, 8 * D, false, true);
+    const TileLayout Lf = tile_layout(D, 1, blocks, nblk, false, 8 * D, false, true);
+    const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, wst, true, true);
+    const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, wst, false, true);
+    return cb.var == VAR_WAVE && cf.var == VAR_WAVE && cb.rt * cb.wgs >= 4 && cf.rt * cf.wgs >= 4;
+}
+
 int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,
              bool use_saved, long rows) {
     int maxO = 0;
@@ -315,9 +361,11 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
             return fail(CSMPN_ERR_INVALID, "block %d: null parameter pointer", k);
         maxO = b.out_features > maxO ? b.out_features : maxO;
     }
-    const int H = decide_h(id, n, blocks, nblk, bwd, stage_rowlen, use_saved, rows);
-    const int NW = 16 / H;
-    const int MT = cdiv(maxO, NW);
+    const bool ps = decide_ps(id, n, blocks, nblk);
+    const int H = ps ? 1 : decide_h(id, n, blocks, nblk, bwd, stage_rowlen, use_saved, rows);
+    const int NW = ps ? 8 : 16 / H;
+    const int MT = ps ? 1 : cdiv(maxO, NW);
+    plan.ps = ps;
     if (MT > 4) return fail(CSMPN_ERR_UNSUPPORTED, "out_features %d > 64 not supported", maxO);
     C.MT = MT;
     C.H = H;
@@ -374,13 +422,14 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     plan.pack_f4 = cursor;
 
     // buffers of one row tile (floats)
-    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved);
+    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps);
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
     C.off_red = L.off_red; C.off_idx = L.off_idx; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
 
     // choose the storage variant, row tiles per workgroup and workgroups per CU
-    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, (size_t)wstore * 4, bwd);
+    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, (size_t)wstore * 4, bwd, ps);
+    if (ps && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: parity-split plan without the single-wave variant");
     if (H == 2 && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: H=2 without the single-wave variant");
     C.RT = ch.rt;
     plan.var = ch.var;
@@ -417,16 +466,33 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    static const int dbg_skip = getenv("CSMPN_DEBUG_SKIP") ? atoi(getenv("CSMPN_DEBUG_SKIP")) : 0;   // timing experiments only
+    io.pad_ = dbg_skip;
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
-    long grid = (ntiles + plan.C.RT - 1) / plan.C.RT;
+    // few tiles (e.g. the node update of a 10k-node complex): fewer row tiles per workgroup,
+    // so that the tiles spread over all CUs instead of filling a few of them
+    DevCemlp Cd = plan.C;
+    unsigned threads = plan.threads;
+    size_t lds_bytes = plan.lds_bytes;
+    if (plan.var != VAR_GLOBAL && Cd.RT > 1 && !bwd) {   // backward: per-workgroup mirror flush outweighs the spread (measured)
+        long rt = (ntiles + 255) / 256;
+        if (rt < 1) rt = 1;
+        if (rt < Cd.RT) {
+            lds_bytes -= (size_t)(Cd.RT - rt) * Cd.tile_floats * 4;
+            Cd.RT = (int)rt;
+            threads = (unsigned)(Cd.RT * Cd.MT * 64);
+        }
+    }
+    long grid = (ntiles + Cd.RT - 1) / Cd.RT;
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
     static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
-                mode, (int)bwd, plan.var, plan.H, plan.C.MT, plan.C.RT, plan.threads, plan.lds_bytes, grid,
-                plan.C.tile_floats, plan.C.mirror_floats, io.rows);
-    HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, plan.threads, plan.lds_bytes, st, plan.C, io));
+        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
+                mode, (int)bwd, plan.var, (int)plan.ps, plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
+                Cd.tile_floats, Cd.mirror_floats, io.rows);
+    if (plan.ps) HIP_TRY(launch_cemlp_ps(id, mode, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
+    else HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
     return CSMPN_OK;
 }
 

@@ -35,57 +35,87 @@ CSMPN_DEV void store_tile_indices(const TileIdx& t, int* tidx, int tid) {
 }
 
 // cooperative gather of the concatenated input rows of one tile into LDS [channel][D][R].
-// Thread mapping: consecutive threads take consecutive 16-byte pieces of ONE row, so a load
-// instruction covers whole rows (256-byte rows: 4 rows = 8 cache lines per wave instruction).
-// A row-per-lane mapping touches 32-64 different lines per instruction and is bound by the
-// address unit (measured: 39 % of the edge forward). The transposing LDS writes are at most
-// 2-way bank conflicts, free for ds_write_b32.
+// Thread mapping: 16 consecutive threads take the (up to 16) 16-byte pieces of ONE row, the
+// thread's row group rg = tid / 16 takes rows rg, rg + RG, rg + 2 RG, ...: a load instruction
+// covers whole rows (256-byte rows of 8 channels x 8 blades: 4 rows = 8 cache lines per wave
+// instruction; a row-per-lane mapping touches 32-64 different lines per instruction and is
+// bound by the address unit), and everything that depends on the piece (channel, blade
+// quarter, LDS column) is computed ONCE per thread and segment - per slot there is one index
+// read, one 64-bit multiply-add and the load (the former element-wise decomposition spent
+// ~100 VALU instructions per slot: 37 % of all instructions of the edge forward).
+// The loads of ALL segments are in flight before the first one is consumed. The transposing
+// LDS writes are at most 2-way bank conflicts, free for ds_write_b32.
 template <class ALG, int H>
-__device__ void stage_input(const RowIO& io, float* tile, const int* tidx, int CP, long row0, int tid, int nthreads) {
+CSMPN_DEV void stage_input(const RowIO& io, float* tile, const int* tidx, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
-    constexpr int DQ = D / 4;   // float4 pieces per channel (power of two)
-    int covered = 0;
+    constexpr int DQ = D / 4;            // float4 pieces per channel (power of two)
+    constexpr int U = R / 4, NS = 3;     // row slots per thread (single-wave tile), segments
+    const int pl = tid & 15, rg = tid >> 4, RG = nthreads >> 4;
+    int covered = 0, most = 0;
     for (int s = 0; s < io.nseg; ++s) {
-        const Seg& sg = io.seg[s];
-        const int ppr = sg.ch * DQ;            // pieces per row
-        const float inv = 1.0f / float(ppr);
-        const int* ta = s == 0 ? tidx : tidx + 2 * R;
-        // batches of U pieces per thread: all loads of a batch are in flight before the first
-        // one is consumed (a plain loop serialises one memory round trip per iteration)
-        constexpr int U = 4;
-        for (int e0 = tid; e0 < R * ppr; e0 += U * nthreads) {
-            f4 v[U];
-            int row[U], p[U];
+        const int ppr = io.seg[s].ch * DQ;
+        most = ppr > most ? ppr : most;
+        covered = io.seg[s].off + io.seg[s].ch;
+    }
+    for (int pb = 0; pb < most; pb += 16) {
+        const int p = pb + pl;
+        f4 v[NS][U], w[U];
+        int dg[U];   // in-degrees of the (single) segment with a mean scale
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int e = e0 + u * nthreads;
-                row[u] = (int)((float(e) + 0.5f) * inv);   // exact: e < 2^20
-                p[u] = e - row[u] * ppr;
-                const long grow = row0 + row[u];
-                v[u] = splat(0.f);
-                if (e < R * ppr && grow < io.rows) {
+        for (int u = 0; u < U; ++u) { w[u] = splat(0.f); dg[u] = 1; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < io.nseg) {
+                const Seg& sg = io.seg[s];
+                const int ppr = sg.ch * DQ;            // pieces per row
+                const bool act = p < ppr;
+                const int* ta = s == 0 ? tidx : tidx + 2 * R;
+                const float* pa = sg.a + (act ? p : 0) * 4;
+                const float* pbp = sg.b ? sg.b + (act ? p : 0) * 4 : nullptr;
+                const unsigned stride = (unsigned)ppr * 4u;   // floats per row
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = rg + RG * u;
+                    const long grow = row0 + row;
+                    const bool ok = act && row < R && grow < io.rows;
                     // the LDS index copies exist for the (at most three) index arrays of
-                    // segments 0/1; segments without an index array are read by row number
-                    const long ra = sg.ia ? (long)ta[row[u]] : grow;
-                    v[u] = *reinterpret_cast<const f4*>(sg.a + (ra * ppr + p[u]) * 4);
-                    if (sg.b) {
-                        const long rb = sg.ib ? (long)tidx[R + row[u]] : grow;
-                        v[u] -= *reinterpret_cast<const f4*>(sg.b + (rb * ppr + p[u]) * 4);
+                    // segments 0/1; segments without an index array are read by row number.
+                    // Invalid slots read row 0 of the table (always there) and are zeroed.
+                    const unsigned ra = ok ? (sg.ia ? (unsigned)ta[row < R ? row : 0] : (unsigned)grow) : 0u;
+                    v[s][u] = *reinterpret_cast<const f4*>(pa + (size_t)ra * stride);
+                    if (s == 0 && pbp) {
+                        const unsigned rb = ok ? (sg.ib ? (unsigned)tidx[R + (row < R ? row : 0)] : (unsigned)grow) : 0u;
+                        w[u] = *reinterpret_cast<const f4*>(pbp + (size_t)rb * stride);
                     }
-                    if (sg.deg) { const int dg = sg.deg[ra]; v[u] *= 1.0f / float(dg > 1 ? dg : 1); }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (e0 + u * nthreads < R * ppr) {
-                    const int dq = p[u] % DQ, ch = p[u] / DQ;
-                    float* q = tile + (sg.off + ch) * CS + (dq * 4) * R + row[u];
-                    q[0] = v[u].x; q[R] = v[u].y; q[2 * R] = v[u].z; q[3 * R] = v[u].w;
+                    if (sg.deg) dg[u] = sg.deg[ra];
+                    if (!ok) v[s][u] = splat(0.f);
                 }
             }
         }
-        covered = sg.off + sg.ch;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < io.nseg) {
+                const Seg& sg = io.seg[s];
+                const int ppr = sg.ch * DQ;
+                if (p < ppr) {
+                    const int dq = p % DQ, ch = p / DQ;
+                    float* q = tile + (sg.off + ch) * CS + (dq * 4) * R + rg;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int row = rg + RG * u;
+                        if (row < R) {
+                            const long grow = row0 + row;
+                            f4 val = v[s][u];
+                            if (s == 0 && sg.b) val = grow < io.rows ? val - w[u] : splat(0.f);
+                            if (sg.deg) val *= 1.0f / float(dg[u] > 1 ? dg[u] : 1);
+                            float* qq = q + RG * u;
+                            qq[0] = val.x; qq[R] = val.y; qq[2 * R] = val.z; qq[3 * R] = val.w;
+                        }
+                    }
+                }
+            }
+        }
     }
     // zero the channel padding
     for (int e = tid; e < (CP - covered) * D * R; e += nthreads) {
@@ -96,33 +126,37 @@ __device__ void stage_input(const RowIO& io, float* tile, const int* tidx, int C
 }
 
 // contiguous rows [rows][ch][D] (a saved block input) -> LDS tile [channel][D][R]; a tile's
-// rows are one contiguous span, read fully coalesced
+// rows are one contiguous span, read fully coalesced; same thread mapping as stage_input
 template <class ALG, int H>
-__device__ void stage_plain(const float* src, int ch, long rows, float* tile, int CP, long row0, int tid, int nthreads) {
+CSMPN_DEV void stage_plain(const float* src, int ch, long rows, float* tile, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
     constexpr int DQ = D / 4;
+    constexpr int U = R / 4;
+    const int pl = tid & 15, rg = tid >> 4, RG = nthreads >> 4;
     const int ppr = ch * DQ;
-    const float inv = 1.0f / float(ppr);
-    const float* base = src + row0 * ppr * 4;
-    constexpr int U = 4;
-    for (int e0 = tid; e0 < R * ppr; e0 += U * nthreads) {
+    for (int pb = 0; pb < ppr; pb += 16) {
+        const int p = pb + pl;
+        const bool act = p < ppr;
+        const float* pa = src + (act ? p : 0) * 4;
         f4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * nthreads;
-            const int row = (int)((float(e) + 0.5f) * inv);
-            v[u] = (e < R * ppr && row0 + row < rows) ? *reinterpret_cast<const f4*>(base + (size_t)e * 4) : splat(0.f);
+            const int row = rg + RG * u;
+            const long grow = row0 + row;
+            const bool ok = act && row < R && grow < rows;
+            v[u] = *reinterpret_cast<const f4*>(pa + (size_t)(ok ? grow : 0) * (size_t)(ppr * 4));
+            if (!ok) v[u] = splat(0.f);
         }
+        if (act) {
+            const int dq = p % DQ, c = p / DQ;
+            float* q = tile + c * CS + (dq * 4) * R + rg;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * nthreads;
-            if (e < R * ppr) {
-                const int row = (int)((float(e) + 0.5f) * inv);
-                const int p = e - row * ppr;
-                const int dq = p % DQ, c = p / DQ;
-                float* q = tile + c * CS + (dq * 4) * R + row;
-                q[0] = v[u].x; q[R] = v[u].y; q[2 * R] = v[u].z; q[3 * R] = v[u].w;
+            for (int u = 0; u < U; ++u) {
+                if (rg + RG * u < R) {
+                    float* qq = q + RG * u;
+                    qq[0] = v[u].x; qq[R] = v[u].y; qq[2 * R] = v[u].z; qq[3 * R] = v[u].w;
+                }
             }
         }
     }
@@ -193,6 +227,49 @@ __device__ void scatter_rows(const float* stage, int rowlen, const int* lidx, fl
             const long target = lidx[row];
             if (target < 0) break;
             for (int f = tid; f < rowlen; f += nthreads) atomicAdd(table + target * rowlen + f, sign * stage[row * rowlen + f]);
+        }
+    }
+}
+
+// Single-wave tiles: the same scatter from registers. The staged tile is read once (every
+// ds_read in flight together), the row targets travel through SGPRs (v_readlane with constant
+// lane), so the loop over the rows has no LDS round trip and only scalar branches. Adds the
+// rows to table[add_idx[row]] (rows sorted by that index: equal consecutive targets are summed
+// first) and, when sub_idx is given, subtracts them from table[sub_idx[row]] (unsorted).
+template <class ALG, int H>
+CSMPN_DEV void scatter_tile(const float* stage, int rowlen, const int* add_idx, const int* sub_idx, float* table,
+                            int lane) {
+    constexpr int R = 16 * H;
+    const int ta = add_idx[lane & (R - 1)];
+    const int tb = sub_idx ? sub_idx[lane & (R - 1)] : -1;
+    // 64 columns of the staged rows at a time (one element per lane and row in registers)
+    for (int e0 = 0; e0 < rowlen; e0 += 64) {
+        const int e = e0 + lane;
+        const bool in = e < rowlen;
+        float val[R];
+#pragma unroll
+        for (int row = 0; row < R; ++row) val[row] = stage[row * rowlen + (in ? e : 0)];
+        auto flush = [&](int target, float a) {
+            if (target >= 0 && in) atomicAdd(table + (long)target * rowlen + e, a);
+        };
+        float acc = val[0];
+        int cur = __builtin_amdgcn_readlane(ta, 0);
+        static_for<1, R>([&](auto rr) {
+            constexpr int row = decltype(rr)::value;
+            const int t = __builtin_amdgcn_readlane(ta, row);
+            if (t != cur) {
+                flush(cur, acc);
+                cur = t;
+                acc = 0.f;
+            }
+            acc += val[row];
+        });
+        flush(cur, acc);
+        if (sub_idx) {
+            static_for<0, R>([&](auto rr) {
+                constexpr int row = decltype(rr)::value;
+                flush(__builtin_amdgcn_readlane(tb, row), -val[row]);
+            });
         }
     }
 }
@@ -318,7 +395,8 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         tile_sync<VAR>();
         // the next tile's indices travel while this tile computes
         nidx = load_tile_indices<R>(io, row0 + tiles_per_iter * R, tid_rt);
-        if (use_saved) {
+        if (io.pad_ & 2) {
+        } else if (use_saved) {
             const DevBlock& Bl = C.b[C.nblk - 1];
             stage_plain<ALG, H>(io.saved + save_off(C.nblk - 1), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
         } else {
@@ -339,7 +417,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR>();
                     store_tile<ALG, H>(out, buf_p(k), B.CPo, mt, ge);
-                    if (io.save) {   // keep the next block's input for the backward
+                    if (io.save && !(io.pad_ & 4)) {   // keep the next block's input for the backward
                         const int cs = NW * mt + ge.cn;
                         if (cs < B.O) {
                             float* sp = io.save + save_off(k + 1);
@@ -365,23 +443,33 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 tile_sync<VAR>();
                 store_dense<ALG, H>(out, buf_g, O, c, ge);
                 tile_sync<VAR>();
-                scatter_rows<ALG, H, !MULTI>(buf_g, O * D, tidx, io.agg, 1.0f, tid_rt, nthr_rt);
+                if (io.pad_ & 1) {}
+                else if constexpr (!MULTI) scatter_tile<ALG, H>(buf_g, O * D, tidx, nullptr, io.agg, lane);
+                else scatter_rows<ALG, H, false>(buf_g, O * D, tidx, io.agg, 1.0f, tid_rt, nthr_rt);
                 tile_sync<VAR>();
                 ge.stamp(18);
             } else {
                 if (c < O) {
+                    // all residual loads first, then all stores: a load behind a store would
+                    // wait for the store's acknowledgement (one vmcnt for both on gfx9)
+                    f4 res[4][D / 4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const long grow = row0 + ge.r0 + v;
+                        const bool ok = MODE == MODE_NODE && io.resid && grow < io.rows;
+#pragma unroll
+                        for (int d4 = 0; d4 < D; d4 += 4)
+                            res[v][d4 / 4] = ok ? *reinterpret_cast<const f4*>(io.resid + (grow * O + c) * D + d4) : splat(0.f);
+                    }
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const long grow = row0 + ge.r0 + v;
                         if (grow < io.rows) {
                             float* p = io.y + (grow * O + c) * D;
 #pragma unroll
-                            for (int d4 = 0; d4 < D; d4 += 4) {
-                                f4 val = f4{out[d4][v], out[d4 + 1][v], out[d4 + 2][v], out[d4 + 3][v]};
-                                if (MODE == MODE_NODE && io.resid)
-                                    val += *reinterpret_cast<const f4*>(io.resid + (grow * O + c) * D + d4);
-                                *reinterpret_cast<f4*>(p + d4) = val;
-                            }
+                            for (int d4 = 0; d4 < D; d4 += 4)
+                                *reinterpret_cast<f4*>(p + d4) =
+                                    f4{out[d4][v], out[d4 + 1][v], out[d4 + 2][v], out[d4 + 3][v]} + res[v][d4 / 4];
                         }
                     }
                 }
@@ -416,7 +504,8 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 const float* in = buf_in;
                 if (use_saved && k + 1 < C.nblk) {
                     // this block's input replaces the previous one in the single input buffer
-                    if (k == 0) stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+                    if (io.pad_ & 2) {}
+                    else if (k == 0) stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
                     else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
                     tile_sync<VAR>();
                     ge.stamp(2);
@@ -503,9 +592,13 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     ge.stamp(17);
                     if constexpr (MODE == MODE_EDGE) {
                         tile_sync<VAR>();
-                        if (io.gx[0]) {
-                            scatter_rows<ALG, H, !MULTI>(stage, Cs0 * D, tidx, io.gx[0], 1.0f, tid_rt, nthr_rt);
-                            scatter_rows<ALG, H, false>(stage, Cs0 * D, tidx + R, io.gx[0], -1.0f, tid_rt, nthr_rt);
+                        if (io.gx[0] && !(io.pad_ & 1)) {
+                            if constexpr (!MULTI) {
+                                scatter_tile<ALG, H>(stage, Cs0 * D, tidx, tidx + R, io.gx[0], lane);
+                            } else {
+                                scatter_rows<ALG, H, false>(stage, Cs0 * D, tidx, io.gx[0], 1.0f, tid_rt, nthr_rt);
+                                scatter_rows<ALG, H, false>(stage, Cs0 * D, tidx + R, io.gx[0], -1.0f, tid_rt, nthr_rt);
+                            }
                         }
                     }
                     tile_sync<VAR>();

@@ -9,6 +9,9 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 
 #define CSMPN_DECLARE_ALG(tag)                                                                                  \
     bool has_h2_##tag();                                                                                        \
+    bool has_ps_##tag();                                                                                        \
+    hipError_t launch_cemlp_ps_##tag(int mode, bool bwd, unsigned grid, unsigned block, size_t lds,            \
+                                     hipStream_t st, const DevCemlp& C, const RowIO& io);                      \
     hipError_t launch_cemlp_##tag(int mode, int var, int h, bool bwd, unsigned grid, unsigned block, size_t lds,   \
                                   hipStream_t st, const DevCemlp& C, const RowIO& io);                          \
     hipError_t launch_gp_##tag(bool bwd, const float* a, const float* b, const float* gout, float* out,        \
