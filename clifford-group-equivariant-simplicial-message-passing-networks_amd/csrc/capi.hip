@@ -147,7 +147,7 @@ __global__ void pack_weights_kernel(const PackDesc P) {
     f4 v;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int k = 16 * kk + 4 * (lane >> 4) + r;
+        const int k = 16 * kk + 4 * r + (lane >> 4);   // k-slot (q, v = r) -> channel 16 kk + 4 v + q
         const int o = S.transposed ? k : n, i = S.transposed ? n : k;
         float val = 0.f;
         if (hcol == hp && o < S.O && i < S.I)

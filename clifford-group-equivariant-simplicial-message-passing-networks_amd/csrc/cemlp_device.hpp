@@ -293,54 +293,116 @@ struct WSrc {
 // acc[d][v] += sum_out T[out][d][row] * W[out][in][grade(d)]       (TRANS = true, acc over in)
 // tile: [channel][D][R] (channel stride CS); CP = valid channels (multiple of 4); nt = this
 // wave's N tile; KK = k-blocks of 16 contracted channels.
-template <class ALG, int H, bool WLDS, bool TRANS>
+template <class ALG, int H, bool WLDS, bool TRANS, bool SPEC = true>
 CSMPN_DEV void linear_from_tile(f4 (&acc)[ALG::D], const float* tile, int CP, int KK, const WSrc& ws, int nt,
                                 const Geo<ALG, H>& ge) {
     using GE = Geo<ALG, H>;
     constexpr int G = ALG::G, R = GE::R, CS = GE::CS, NW = GE::NW;
     const f4* fbase = ws.frags + (size_t)nt * KK * (H * G * 64) + ge.lane;
     const int ncol = NW * nt + ge.cn;   // this lane's output channel of the product
+    // k-slot (q, v) of k-block kk is contracted channel 16*kk + 4*v + q: MFMA number v covers
+    // the four CONSECUTIVE channels 4v..4v+3, so a block of 8 valid channels (the 8-channel
+    // layers) issues 2 MFMAs per blade, not 4 with half of every k dimension on padding.
     // All LDS reads below are UNCONDITIONAL from clamped (always valid, finite) addresses:
     // a k-slot beyond the tile's channels contributes nothing because its B fragment (the
     // weight) is zero there. Predicated reads would compile to an exec-mask branch plus a
     // full s_waitcnt in front of every single MFMA.
     for (int kk = 0; kk < KK; ++kk) {
-        const int c0 = 16 * kk + 4 * ge.q;
+        const int c0 = 16 * kk + ge.q;
+        const int left = CP - 16 * kk;               // valid channels of this k-block (multiple of 4)
+        const int nv = left >= 16 ? 4 : left / 4;    // MFMAs per blade
         const float* ap = tile + (c0 < CP ? c0 : 0) * CS + ge.n;
+        // one straight-line body per MFMA count (branches inside it would stop the scheduler
+        // from batching the LDS reads in front of the MFMAs)
+        auto body = [&](auto NVc) {
+            constexpr int NV = decltype(NVc)::value;
 #pragma unroll
-        for (int hp = 0; hp < H; ++hp) {
-            static_for<0, G>([&](auto g) {
-                f4 b;
-                if constexpr (!WLDS) {
-                    b = fbase[(size_t)kk * (H * G * 64) + (hp * G + g) * 64];
-                } else {
-                    const int gi = ws.grades ? int(g) : 0;
-                    const bool half_ok = H == 1 || ge.h == hp;
-                    if constexpr (!TRANS) {
-                        const float okf = (half_ok && ncol < ws.O && c0 < ws.IP) ? 1.0f : 0.0f;
-                        const int oc = ncol < ws.O ? ncol : 0, ic = c0 < ws.IP ? c0 : 0;
-                        b = *reinterpret_cast<const f4*>(ws.w + (gi * ws.O + oc) * ws.IP + ic) * okf;
+            for (int hp = 0; hp < H; ++hp) {
+                static_for<0, G>([&](auto g) {
+                    f4 b;
+                    if constexpr (!WLDS) {
+                        b = fbase[(size_t)kk * (H * G * 64) + (hp * G + g) * 64];
                     } else {
-                        const bool okc = half_ok && ncol < ws.IP;
-                        const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
+                        const int gi = ws.grades ? int(g) : 0;
+                        const bool half_ok = H == 1 || ge.h == hp;
+                        if constexpr (!TRANS) {
+                            const bool okc = half_ok && ncol < ws.O;
+                            const float* wp = ws.w + (gi * ws.O + (ncol < ws.O ? ncol : 0)) * ws.IP;
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            const int o = c0 + v;
-                            b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                            for (int v = 0; v < NV; ++v) {
+                                const int i = c0 + 4 * v;
+                                b[v] = wp[i < ws.IP ? i : 0] * ((okc && i < ws.IP) ? 1.0f : 0.0f);
+                            }
+                        } else {
+                            const bool okc = half_ok && ncol < ws.IP;
+                            const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) {
+                                const int o = c0 + 4 * v;
+                                b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                            }
                         }
                     }
-                }
-                constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-                float a[4][nd];
+                    constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+                    float a[NV][nd];
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int t = 0; t < nd; ++t) a[v][t] = ap[v * CS + (d0 + t) * R + 16 * hp];
+                        for (int t = 0; t < nd; ++t) a[v][t] = ap[(4 * v < left ? 4 * v : 0) * CS + (d0 + t) * R + 16 * hp];
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+                    for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int t = 0; t < nd; ++t) acc[d0 + t] = mfma16(a[v][t], b[v], acc[d0 + t]);
-            });
+                        for (int t = 0; t < nd; ++t) acc[d0 + t] = mfma16(a[v][t], b[v], acc[d0 + t]);
+                });
+            }
+        };
+        // SPEC (backward kernels, one wave per SIMD): two straight-line bodies; the 4-MFMA one
+        // also serves 1 and 3 (clamped reads times zero weights). Otherwise (forward kernels,
+        // tight on registers and code size) one body with wave-uniform guards per MFMA group.
+        if constexpr (SPEC) {
+            if (nv == 2) body(IC<2>{});
+            else body(IC<4>{});
+        } else {
+#pragma unroll
+            for (int hp = 0; hp < H; ++hp) {
+                static_for<0, G>([&](auto g) {
+                    f4 b;
+                    if constexpr (!WLDS) {
+                        b = fbase[(size_t)kk * (H * G * 64) + (hp * G + g) * 64];
+                    } else {
+                        const int gi = ws.grades ? int(g) : 0;
+                        const bool half_ok = H == 1 || ge.h == hp;
+                        if constexpr (!TRANS) {
+                            const bool okc = half_ok && ncol < ws.O;
+                            const float* wp = ws.w + (gi * ws.O + (ncol < ws.O ? ncol : 0)) * ws.IP;
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int i = c0 + 4 * v;
+                                b[v] = wp[i < ws.IP ? i : 0] * ((okc && i < ws.IP) ? 1.0f : 0.0f);
+                            }
+                        } else {
+                            const bool okc = half_ok && ncol < ws.IP;
+                            const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const int o = c0 + 4 * v;
+                                b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                            }
+                        }
+                    }
+                    constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        if (v < nv) {   // wave-uniform
+                            float a[nd];
+#pragma unroll
+                            for (int t = 0; t < nd; ++t) a[t] = ap[4 * v * CS + (d0 + t) * R + 16 * hp];
+#pragma unroll
+                            for (int t = 0; t < nd; ++t) acc[d0 + t] = mfma16(a[t], b[v], acc[d0 + t]);
+                        }
+                    }
+                });
+            }
         }
     }
 }
@@ -564,7 +626,7 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 // block forward. Input tile in LDS (xin), output in lane layout (out) for this wave's
 // channel tile. zbuf: LDS tile for the gated activations (feeds linear_left/right).
 // red: scratch [MT][16] floats for cross-wave LayerNorm sums (barrier variants only).
-template <class ALG, int H, int VAR>
+template <class ALG, int H, int VAR, bool SPEC = true>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
                              float* red, const float* wstore, int MT, int mt, const Geo<ALG, H>& ge,
                              FwdState<ALG>& S, f4 (&out)[ALG::D]) {
@@ -582,7 +644,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     // 1. MVLinear (cegnn_utils.py:326-338)
 #pragma unroll
     for (int d = 0; d < D; ++d) S.y[d] = splat(0.f);
-    if (tile_active) linear_from_tile<ALG, H, WLDS, false>(S.y, xin, B.CPi, B.KKi, sW1, mt, ge);
+    if (tile_active) linear_from_tile<ALG, H, WLDS, false, SPEC>(S.y, xin, B.CPi, B.KKi, sW1, mt, ge);
     S.y[0] += lp.b1;
     ge.stamp(3);
 
@@ -618,8 +680,8 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
 #pragma unroll
     for (int d = 0; d < D; ++d) { S.R[d] = splat(0.f); L[d] = splat(0.f); }
     if (tile_active) {
-        linear_from_tile<ALG, H, WLDS, false>(S.R, zbuf, B.CPo, B.KKo, sWR, mt, ge);
-        linear_from_tile<ALG, H, WLDS, false>(L, zbuf, B.CPo, B.KKo, sWL, mt, ge);
+        linear_from_tile<ALG, H, WLDS, false, SPEC>(S.R, zbuf, B.CPo, B.KKo, sWR, mt, ge);
+        linear_from_tile<ALG, H, WLDS, false, SPEC>(L, zbuf, B.CPo, B.KKo, sWL, mt, ge);
     }
     L[0] += lp.bL;
     ge.stamp(5);

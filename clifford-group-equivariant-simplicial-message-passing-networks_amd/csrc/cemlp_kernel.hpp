@@ -45,12 +45,12 @@ CSMPN_DEV void store_tile_indices(const TileIdx& t, int* tidx, int tid) {
 // ~100 VALU instructions per slot: 37 % of all instructions of the edge forward).
 // The loads of ALL segments are in flight before the first one is consumed. The transposing
 // LDS writes are at most 2-way bank conflicts, free for ds_write_b32.
-template <class ALG, int H>
+template <class ALG, int H, int NS>
 CSMPN_DEV void stage_input(const RowIO& io, float* tile, const int* tidx, int CP, long row0, int tid, int nthreads) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, R = GE::R, CS = GE::CS;
     constexpr int DQ = D / 4;            // float4 pieces per channel (power of two)
-    constexpr int U = R / 4, NS = 3;     // row slots per thread (single-wave tile), segments
+    constexpr int U = R / 4;             // row slots per thread (single-wave tile); NS = segments of the mode
     const int pl = tid & 15, rg = tid >> 4, RG = nthreads >> 4;
     int covered = 0, most = 0;
     for (int s = 0; s < io.nseg; ++s) {
@@ -242,35 +242,40 @@ CSMPN_DEV void scatter_tile(const float* stage, int rowlen, const int* add_idx, 
     constexpr int R = 16 * H;
     const int ta = add_idx[lane & (R - 1)];
     const int tb = sub_idx ? sub_idx[lane & (R - 1)] : -1;
-    // 64 columns of the staged rows at a time (one element per lane and row in registers)
+    // 64 columns of the staged rows at a time, 16 rows per batch of LDS reads (one element per
+    // lane and row in registers)
     for (int e0 = 0; e0 < rowlen; e0 += 64) {
         const int e = e0 + lane;
         const bool in = e < rowlen;
-        float val[R];
-#pragma unroll
-        for (int row = 0; row < R; ++row) val[row] = stage[row * rowlen + (in ? e : 0)];
+        const float* col = stage + (in ? e : 0);
         auto flush = [&](int target, float a) {
             if (target >= 0 && in) atomicAdd(table + (long)target * rowlen + e, a);
         };
-        float acc = val[0];
+        float acc = 0.f;
         int cur = __builtin_amdgcn_readlane(ta, 0);
-        static_for<1, R>([&](auto rr) {
-            constexpr int row = decltype(rr)::value;
-            const int t = __builtin_amdgcn_readlane(ta, row);
-            if (t != cur) {
-                flush(cur, acc);
-                cur = t;
-                acc = 0.f;
+        static_for<0, R / 16>([&](auto gg) {
+            constexpr int r0 = 16 * decltype(gg)::value;
+            float val[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) val[i] = col[(r0 + i) * rowlen];
+            static_for<0, 16>([&](auto rr) {
+                constexpr int row = r0 + decltype(rr)::value;
+                const int t = __builtin_amdgcn_readlane(ta, row);
+                if (t != cur) {
+                    flush(cur, acc);
+                    cur = t;
+                    acc = 0.f;
+                }
+                acc += val[decltype(rr)::value];
+            });
+            if (sub_idx) {
+                static_for<0, 16>([&](auto rr) {
+                    constexpr int row = r0 + decltype(rr)::value;
+                    flush(__builtin_amdgcn_readlane(tb, row), -val[decltype(rr)::value]);
+                });
             }
-            acc += val[row];
         });
         flush(cur, acc);
-        if (sub_idx) {
-            static_for<0, R>([&](auto rr) {
-                constexpr int row = decltype(rr)::value;
-                flush(__builtin_amdgcn_readlane(tb, row), -val[row]);
-            });
-        }
     }
 }
 
@@ -299,6 +304,9 @@ CSMPN_DEV void unpark(f4 (&t)[ALG::D], const float* area, int lane) {
 #pragma unroll
     for (int d = 0; d < ALG::D; ++d) t[d] = *reinterpret_cast<const f4*>(area + (d * 64 + lane) * 4);
 }
+
+// concatenated input segments per mode: CEMLP rows / [h_i - h_j | edge_attr] / [h | agg | node_attr]
+template <int MODE> constexpr int kModeSegs = MODE == MODE_PLAIN ? 1 : (MODE == MODE_EDGE ? 2 : 3);
 
 // Forward: 512 threads (2 waves/SIMD at <=256 VGPRs). Backward keeps the whole forward
 // state of a block live: 256 threads (1 wave/SIMD, up to 512 VGPRs).
@@ -400,7 +408,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
             const DevBlock& Bl = C.b[C.nblk - 1];
             stage_plain<ALG, H>(io.saved + save_off(C.nblk - 1), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
         } else {
-            stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+            stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
         }
         tile_sync<VAR>();
         ge.stamp(0);
@@ -413,7 +421,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 const DevBlock& B = C.b[k];
                 const LaneParams<ALG> lp = lane_params(B, NW * mt + ge.cn);
                 FwdState<ALG> S;
-                block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, out);
+                block_forward<ALG, H, VAR, BWD>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, out);
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR>();
                     store_tile<ALG, H>(out, buf_p(k), B.CPo, mt, ge);
@@ -505,7 +513,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 if (use_saved && k + 1 < C.nblk) {
                     // this block's input replaces the previous one in the single input buffer
                     if (io.pad_ & 2) {}
-                    else if (k == 0) stage_input<ALG, H>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+                    else if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
                     else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
                     tile_sync<VAR>();
                     ge.stamp(2);
@@ -516,7 +524,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     const LaneParams<ALG> lpj = lane_params(Bj, NW * mt + ge.cn);
                     FwdState<ALG> Sj;
                     f4 oj[D];
-                    block_forward<ALG, H, VAR>(Bj, lpj, in, buf_z, red, wstore, MT, mt, ge, Sj, oj);
+                    block_forward<ALG, H, VAR, BWD>(Bj, lpj, in, buf_z, red, wstore, MT, mt, ge, Sj, oj);
                     tile_sync<VAR>();
                     store_tile<ALG, H>(oj, buf_p(j), Bj.CPo, mt, ge);
                     tile_sync<VAR>();
@@ -528,7 +536,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 {
                     FwdState<ALG> S;
                     f4 unused[D];
-                    block_forward<ALG, H, VAR>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused);
+                    block_forward<ALG, H, VAR, BWD>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused);
                     if constexpr (PARK) { tile_sync<VAR>(); unpark<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
                     block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy);
                 }

@@ -161,38 +161,50 @@ CSMPN_DEV void ps_linear(f4 (&acc)[PS<ALG>::DL], const float* tile, int CP, int 
     using P = PS<ALG>;
     constexpr int G = ALG::G, R = P::R, CS = P::CS, NW = P::NW;
     const int ncol = NW * nt + ge.cn;
+    // k-slot (q, v) of k-block kk is contracted channel 16*kk + 4*v + q (see linear_from_tile)
     for (int kk = 0; kk < KK; ++kk) {
-        const int c0 = 16 * kk + 4 * ge.q;
+        const int c0 = 16 * kk + ge.q;
+        const int left = CP - 16 * kk;
+        const int nv = left >= 16 ? 4 : left / 4;
         const float* ap = tile + (c0 < CP ? c0 : 0) * CS + ge.n;
-        static_for<0, G>([&](auto g) {
-            f4 b;
-            const int gi = ws.grades ? int(g) : 0;
-            const bool mine = ge.s == (int(g) & 1);
-            if constexpr (!TRANS) {
-                const float okf = (mine && ncol < ws.O && c0 < ws.IP) ? 1.0f : 0.0f;
-                const int oc = ncol < ws.O ? ncol : 0, ic = c0 < ws.IP ? c0 : 0;
-                b = *reinterpret_cast<const f4*>(ws.w + (gi * ws.O + oc) * ws.IP + ic) * okf;
-            } else {
-                const bool okc = mine && ncol < ws.IP;
-                const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
+        auto body = [&](auto NVc) {
+            constexpr int NV = decltype(NVc)::value;
+            static_for<0, G>([&](auto g) {
+                f4 b;
+                const int gi = ws.grades ? int(g) : 0;
+                const bool mine = ge.s == (int(g) & 1);
+                if constexpr (!TRANS) {
+                    const bool okc = mine && ncol < ws.O;
+                    const float* wp = ws.w + (gi * ws.O + (ncol < ws.O ? ncol : 0)) * ws.IP;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int o = c0 + v;
-                    b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                    for (int v = 0; v < NV; ++v) {
+                        const int i = c0 + 4 * v;
+                        b[v] = wp[i < ws.IP ? i : 0] * ((okc && i < ws.IP) ? 1.0f : 0.0f);
+                    }
+                } else {
+                    const bool okc = mine && ncol < ws.IP;
+                    const float* wp = ws.w + gi * ws.O * ws.IP + (ncol < ws.IP ? ncol : 0);
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const int o = c0 + 4 * v;
+                        b[v] = wp[(o < ws.O ? o : 0) * ws.IP] * ((okc && o < ws.O) ? 1.0f : 0.0f);
+                    }
                 }
-            }
-            constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-            float a[4][nd];
+                constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+                float a[NV][nd];
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+                for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int t = 0; t < nd; ++t) a[v][t] = ap[v * CS + (d0 + t) * R];
-            static_for<0, nd>([&](auto tt) {
-                constexpr int sl = P::t.slot[d0 + decltype(tt)::value];
+                    for (int t = 0; t < nd; ++t) a[v][t] = ap[(4 * v < left ? 4 * v : 0) * CS + (d0 + t) * R];
+                static_for<0, nd>([&](auto tt) {
+                    constexpr int sl = P::t.slot[d0 + decltype(tt)::value];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[sl] = mfma16(a[v][decltype(tt)::value], b[v], acc[sl]);
+                    for (int v = 0; v < NV; ++v) acc[sl] = mfma16(a[v][decltype(tt)::value], b[v], acc[sl]);
+                });
             });
-        });
+        };
+        if (nv == 2) body(IC<2>{});
+        else body(IC<4>{});
     }
 }
 
@@ -820,7 +832,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
         } else if (use_saved) {
             stage_plain<ALG, 1>(io.saved + save_off(C.nblk - 1), BL.I, io.rows, buf_in, BL.CPi, row0, lane, 64);
         } else {
-            stage_input<ALG, 1>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
+            stage_input<ALG, 1, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
         }
         tile_sync<VAR_WAVE>();
 
@@ -902,7 +914,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
                 const float* in = buf_in;
                 if (use_saved && k + 1 < C.nblk) {
                     if (io.pad_ & 2) {}
-                    else if (k == 0) stage_input<ALG, 1>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
+                    else if (k == 0) stage_input<ALG, 1, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
                     else stage_plain<ALG, 1>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, lane, 64);
                     tile_sync<VAR_WAVE>();
                 }
