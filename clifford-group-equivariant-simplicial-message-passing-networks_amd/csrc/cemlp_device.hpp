@@ -194,11 +194,12 @@ CSMPN_DEV float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 // H = 2, the two row halves (lane columns n and n^8: one DPP rotate). Result in every lane.
 template <int H>
 CSMPN_DEV float channel_rows_sum(float v) {
-    // lanes l and l^32: ds_bpermute (hipcc mis-selects the second result of
-    // __builtin_amdgcn_permlane32_swap when both operands carry the same value)
-    const float s = v + __shfl_xor(v, 32);
-    // swizzle, bit-mask mode: and 0x1F, or 0, xor 0x10  ->  lane ^ 16 inside each 32-lane group
-    float t = s + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), 0x401F));
+    // One MFMA with A = 1: D[i][j] = sum_k B[k][j], and B[k = q][j = n] is this value in lane
+    // (n, q) - every lane receives the sum over the 4 row quarters of its own column (exact
+    // fp32 FMA chain). The LDS-crossbar form (ds_bpermute + ds_swizzle per value, 35 values per
+    // block) cost 7 % of the edge backward in exposed LDS latency.
+    const f4 r = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    float t = r.x;
     if constexpr (H == 2) t += dpp_mov<0x128>(t);   // row_ror 8: the other half's column
     return t;
 }

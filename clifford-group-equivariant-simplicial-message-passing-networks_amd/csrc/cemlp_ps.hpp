@@ -145,8 +145,8 @@ CSMPN_DEV f4 odd4(f4 v) {
 }
 // sum over the 4 row quarters of a lane column (no partner add: the partner lane holds other parameters)
 CSMPN_DEV float quarter_sum(float v) {
-    const float s = v + __shfl_xor(v, 32);
-    return s + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, s), 0x401F));
+    const f4 r = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, splat(0.f), 0, 0, 0);   // see channel_rows_sum
+    return r.x;
 }
 
 // ---------------------------------------------------------------------------------
