@@ -57,7 +57,9 @@ def pmc_traffic(stage):
     same workload (separate --pmc passes, tools/profile_r01.sh): 2 x FETCH_SIZE (gfx950 counts a
     wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> B.
     None when no summary is committed (counters cannot be read from inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r01_v4_pmc_summary.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    path = found[-1] if found else ""   # the latest committed summary
     tag = {"edge_fwd": "1, 0, 2, false", "edge_bwd": "1, 0, 2, true", "node_fwd": "2, 0, 1, false",
            "node_bwd": "2, 0, 1, true"}.get(stage)
     try:
