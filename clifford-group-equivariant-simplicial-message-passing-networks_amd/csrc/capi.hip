@@ -228,7 +228,7 @@ struct Choice { int var, rt, wgs; bool mirror; };
 Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wstore_bytes, bool bwd, bool ps = false) {
     // workgroups of at most 512 threads (forward, parity-split backward) / 256 threads (backward)
     // parity-split forward: 256-thread workgroups, three per CU (168 VGPRs: 3 waves per SIMD)
-    const int waves = ps ? (bwd ? 8 : 4) : (bwd ? 4 : 8);
+    const int waves = ps ? 4 : (bwd ? 4 : 8);
     const int max_wgs = (ps && !bwd) ? 3 : 2;
     const int max_rt = (waves / MT) > 0 ? waves / MT : 1;
     auto fit = [&](size_t fixed, int& rt_out, int& wgs_out) {
@@ -466,8 +466,6 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
-    static const int dbg_skip = getenv("CSMPN_DEBUG_SKIP") ? atoi(getenv("CSMPN_DEBUG_SKIP")) : 0;   // timing experiments only
-    io.pad_ = dbg_skip;
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
     // few tiles (e.g. the node update of a 10k-node complex): fewer row tiles per workgroup,

@@ -403,8 +403,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         tile_sync<VAR>();
         // the next tile's indices travel while this tile computes
         nidx = load_tile_indices<R>(io, row0 + tiles_per_iter * R, tid_rt);
-        if (io.pad_ & 2) {
-        } else if (use_saved) {
+        if (use_saved) {
             const DevBlock& Bl = C.b[C.nblk - 1];
             stage_plain<ALG, H>(io.saved + save_off(C.nblk - 1), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
         } else {
@@ -425,7 +424,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR>();
                     store_tile<ALG, H>(out, buf_p(k), B.CPo, mt, ge);
-                    if (io.save && !(io.pad_ & 4)) {   // keep the next block's input for the backward
+                    if (io.save) {   // keep the next block's input for the backward
                         const int cs = NW * mt + ge.cn;
                         if (cs < B.O) {
                             float* sp = io.save + save_off(k + 1);
@@ -451,8 +450,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 tile_sync<VAR>();
                 store_dense<ALG, H>(out, buf_g, O, c, ge);
                 tile_sync<VAR>();
-                if (io.pad_ & 1) {}
-                else if constexpr (!MULTI) scatter_tile<ALG, H>(buf_g, O * D, tidx, nullptr, io.agg, lane);
+                if constexpr (!MULTI) scatter_tile<ALG, H>(buf_g, O * D, tidx, nullptr, io.agg, lane);
                 else scatter_rows<ALG, H, false>(buf_g, O * D, tidx, io.agg, 1.0f, tid_rt, nthr_rt);
                 tile_sync<VAR>();
                 ge.stamp(18);
@@ -512,8 +510,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 const float* in = buf_in;
                 if (use_saved && k + 1 < C.nblk) {
                     // this block's input replaces the previous one in the single input buffer
-                    if (io.pad_ & 2) {}
-                    else if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+                    if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
                     else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
                     tile_sync<VAR>();
                     ge.stamp(2);
@@ -600,7 +597,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     ge.stamp(17);
                     if constexpr (MODE == MODE_EDGE) {
                         tile_sync<VAR>();
-                        if (io.gx[0] && !(io.pad_ & 1)) {
+                        if (io.gx[0]) {
                             if constexpr (!MULTI) {
                                 scatter_tile<ALG, H>(stage, Cs0 * D, tidx, tidx + R, io.gx[0], lane);
                             } else {

@@ -759,7 +759,7 @@ CSMPN_DEV void ps_block_backward(const DevBlock& B, const PSLaneParams<ALG>& lp,
 // Forward: 512 threads per workgroup (VGPRs bounded to 128: 4 waves per SIMD with two
 // workgroups per CU); backward: 512 threads (256 VGPRs: 2 waves per SIMD).
 template <class ALG, int MODE, bool BWD>
-__global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(256, BWD ? 1 : 3) cemlp_ps_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
@@ -828,8 +828,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
         store_tile_indices<R>(nidx, tidx, lane);
         tile_sync<VAR_WAVE>();
         nidx = load_tile_indices<R>(io, row0 + tiles_per_iter * R, lane);
-        if (io.pad_ & 2) {
-        } else if (use_saved) {
+        if (use_saved) {
             stage_plain<ALG, 1>(io.saved + save_off(C.nblk - 1), BL.I, io.rows, buf_in, BL.CPi, row0, lane, 64);
         } else {
             stage_input<ALG, 1, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
@@ -847,7 +846,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
                 if (k + 1 < C.nblk) {
                     tile_sync<VAR_WAVE>();
                     ps_store_tile<ALG>(out, buf_p0, B.CPo, ge);
-                    if (io.save && c < B.O && !(io.pad_ & 4)) {
+                    if (io.save && c < B.O) {
                         float* sp = io.save + save_off(k + 1);
                         static_for<0, DL>([&](auto jj) {
                             constexpr int j = decltype(jj)::value;
@@ -868,7 +867,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
                 tile_sync<VAR_WAVE>();
                 ps_store_dense<ALG>(out, buf_g, O, c, ge);
                 tile_sync<VAR_WAVE>();
-                if (!(io.pad_ & 1)) scatter_tile<ALG, 1>(buf_g, O * D, tidx, nullptr, io.agg, lane);
+                scatter_tile<ALG, 1>(buf_g, O * D, tidx, nullptr, io.agg, lane);
                 tile_sync<VAR_WAVE>();
             } else {
                 if (c < O) {
@@ -913,8 +912,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
                 const DevBlock& B = C.b[k];
                 const float* in = buf_in;
                 if (use_saved && k + 1 < C.nblk) {
-                    if (io.pad_ & 2) {}
-                    else if (k == 0) stage_input<ALG, 1, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
+                    if (k == 0) stage_input<ALG, 1, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, lane, 64);
                     else stage_plain<ALG, 1>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, lane, 64);
                     tile_sync<VAR_WAVE>();
                 }
@@ -992,7 +990,7 @@ __global__ void __launch_bounds__(BWD ? 512 : 256, BWD ? 2 : 3) cemlp_ps_kernel(
                     }
                     if constexpr (MODE == MODE_EDGE) {
                         tile_sync<VAR_WAVE>();
-                        if (io.gx[0] && !(io.pad_ & 1)) scatter_tile<ALG, 1>(stage, Cs0 * D, tidx, tidx + R, io.gx[0], lane);
+                        if (io.gx[0]) scatter_tile<ALG, 1>(stage, Cs0 * D, tidx, tidx + R, io.gx[0], lane);
                     }
                     tile_sync<VAR_WAVE>();
                 }
