@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--workload", default="S1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--segments", action="store_true",
+                    help="run the N>1 launch path (graph segments + eager collectives) on one GPU too")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work")
     args = ap.parse_args()
 
@@ -163,7 +165,8 @@ def main():
     h.requires_grad_(True)
     gout = torch.ones(N, C, D, device=device)
 
-    if world > 1:
+    segments = None
+    if world > 1 or args.segments:
         sl = sharded.ShardedEGCL(layer)
         plan = sl.plan(ei, N)
 
@@ -180,8 +183,18 @@ def main():
         step()
     torch.cuda.synchronize()
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (world == 1) and not args.no_graph and not args.segments
     graph = None
+    if (world > 1 or args.segments) and not args.no_graph:
+        # compute stages as two HIP graphs, the two collectives eager between them
+        try:
+            segments = sharded.GraphedShardedStep(sl, plan, h, ea, na, gout)
+            segments.run()
+            torch.cuda.synchronize()
+        except Exception as exc:
+            print(f"[bench] graph segments unavailable ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
+            segments = None
+            torch.cuda.synchronize()
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
@@ -194,7 +207,7 @@ def main():
                   file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+    run = graph.replay if graph is not None else (segments.run if segments is not None else step)
     for _ in range(2):
         run()
 
@@ -268,7 +281,8 @@ def main():
             "config": {"workload": f"{args.workload}: EGCL layer fwd+bwd, Cl{tuple(int(m) for m in metric)}, "
                                    f"{C} channels, {N} nodes, {E_per} edges/GPU x {world} GPU, aggr=mean, "
                                    f"edge_attr 6ch, node_attr 3ch",
-                       "launch": "hip-graph replay" if graph is not None else "eager",
+                       "launch": ("hip-graph replay" if graph is not None else
+                                  "hip-graph segments + eager collectives" if segments is not None else "eager"),
                        "sharding": "edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"
                                    if world > 1 else "none"},
             "roofline": roofline,

@@ -321,3 +321,34 @@ def test_saved_inputs_vs_recompute(pkg):
         res.append([out, gh] + [g for g in ge + gn if g is not None])
     for a, b in zip(*res):
         assert relmax(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
+def test_graphed_sharded_step_matches_autograd(pkg):
+    """The fixed-buffer step of the sharded layer (two HIP graphs, collectives between them; here
+    world size 1, so no collective) returns what the autograd path of the plain layer returns."""
+    from csmpn_hip import sharded
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra((1.0, 1.0, 1.0)), 8, 8, 8, edge_attr_features=6, node_attr_features=3,
+                     aggr="mean").to(dev)
+    N, E = 300, 4001
+    h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), N, E, 8, seed=3))
+    gout = torch.randn(N, 8, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+    params = list(layer.parameters())
+    h2 = h.clone().requires_grad_(True)
+    y2 = layer(h2, ei, ea, na)
+    g2 = torch.autograd.grad(y2, [h2] + params, gout)
+    sl = sharded.ShardedEGCL(layer)
+    plan = sl.plan(ei, N)
+    st = sharded.GraphedShardedStep(sl, plan, h, ea, na, gout)
+    for _ in range(2):   # replays must not accumulate
+        st.run()
+    torch.cuda.synchronize()
+    out, gh, ge, gn = st.results()
+    rel = lambda a, b: float((a.detach() - b.detach()).abs().max() / b.detach().abs().max().clamp(min=1e-30))
+    assert rel(out, y2) < 2e-5 and rel(gh, g2[0]) < 2e-5
+    flat = layer.edge_model.flat_params() + layer.node_model.flat_params()
+    by_id = {id(p): g for p, g in zip(params, g2[1:])}
+    for p, g in zip(flat, ge + gn):
+        if p is not None:
+            assert rel(g, by_id[id(p)]) < 2e-5
