@@ -168,9 +168,10 @@ class GraphedShardedStep:
         torch.cuda.synchronize()
 
         self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g1):
+        # thread-local capture mode: the process group's watchdog thread polls events while we capture
+        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
             self.agg, self._st_e = part1()
-        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+        with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
             self.out, self.gh_node, self.packed, views_e, self.views_n = part2(self.agg, self._st_e)
         self._edge_shapes = [None if v is None else tuple(v.shape) for v in views_e]
         self.gh = torch.empty_like(h_)
