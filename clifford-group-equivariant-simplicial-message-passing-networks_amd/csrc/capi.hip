@@ -218,7 +218,9 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
         if (MT == 1 && park > sz_g) sz_g = park;
         off += sz_g;
     }
-    L.off_red = off; off += MT > 1 ? rup(MT * 16, 4) : 0;
+    // cross-wave LayerNorm scratch of the barrier variants: reserved for single-wave tiles too (they
+    // run a barrier variant when the weight store does not fit beside the tiles, or in global scratch)
+    L.off_red = off; off += rup(MT * 16, 4);
     L.off_idx = off; off += rup(3 * R, 4);   // int copies of the tile's gathered row indices
     L.total = off;
     return L;
@@ -245,16 +247,17 @@ Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wst
     };
     Choice c{VAR_GLOBAL, 1, 1, false};
     int rt = 0, wgs = 1;
+    static const int min_lds_waves = getenv("CSMPN_MIN_LDS_TILES") ? atoi(getenv("CSMPN_MIN_LDS_TILES")) : 1;
     // single-wave tiles with gradient mirror and weight store in LDS
-    if (MT == 1 && fit(mirror_bytes + wstore_bytes, rt, wgs)) {
+    if (MT == 1 && fit(mirror_bytes + wstore_bytes, rt, wgs) && rt * wgs >= min_lds_waves) {
         c.var = VAR_WAVE; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
         return c;
     }
-    if (fit(mirror_bytes, rt, wgs)) {
+    if (fit(mirror_bytes, rt, wgs) && rt * wgs >= min_lds_waves) {
         c.var = VAR_GROUP; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
         return c;
     }
-    if (fit(0, rt, wgs)) {   // tiles fit, the gradient mirror does not
+    if (fit(0, rt, wgs) && rt * wgs >= min_lds_waves) {   // tiles fit, the gradient mirror does not
         c.var = VAR_GROUP_NM; c.rt = rt; c.wgs = wgs; c.mirror = false;
         return c;
     }
@@ -648,10 +651,14 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
     const TileLayout Lf = tile_layout(D, 1, blocks, n_blocks, false, blocks[n_blocks - 1].out_features * D);
     const Choice cb = choose_variant(MT, (size_t)Lb.total * 4, 0, 0, true);
     const Choice cf = choose_variant(MT, (size_t)Lf.total * 4, 0, 0, false);
+    // global tile scratch: reserved whenever a launch may choose it (the choice itself needs the
+    // metric: path count -> mirror / weight-store size), i.e. for every tile too big to have a
+    // few copies in LDS
     size_t scratch = 0;
-    if (cb.var == VAR_GLOBAL) scratch = (size_t)kGlobalTileGrid * cb.rt * Lb.total * 4;
-    if (cf.var == VAR_GLOBAL) {
-        const size_t s2 = (size_t)kGlobalTileGrid * cf.rt * Lf.total * 4;
+    const int grt = (4 / MT) > 0 ? 4 / MT : 1;
+    if (cb.var == VAR_GLOBAL || (size_t)Lb.total * 4 > 36 * 1024) scratch = (size_t)kGlobalTileGrid * grt * Lb.total * 4;
+    if (cf.var == VAR_GLOBAL || (size_t)Lf.total * 4 > 36 * 1024) {
+        const size_t s2 = (size_t)kGlobalTileGrid * grt * Lf.total * 4;
         scratch = s2 > scratch ? s2 : scratch;
     }
     return bytes + scratch;
@@ -681,7 +688,10 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     Plan plan;
     int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, rows, plan);
     if (rc) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    // fragments packed by the forward are only valid for the forward's own layout choice (a forward
+    // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
+    (void)flags;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
@@ -749,7 +759,10 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     Plan plan;
     int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, E, plan);
     if (rc) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    // fragments packed by the forward are only valid for the forward's own layout choice (a forward
+    // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
+    (void)flags;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
@@ -811,7 +824,10 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, N, plan))) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    // fragments packed by the forward are only valid for the forward's own layout choice (a forward
+    // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
+    (void)flags;
+    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
     return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream);
