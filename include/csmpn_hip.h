@@ -48,9 +48,11 @@ extern "C" {
 #define CSMPN_ERR_HIP 3
 
 /* flags of the compute entry points */
-#define CSMPN_FLAG_WEIGHTS_PACKED 1u /* workspace already holds this CEMLP's packed weights
-                                       (left there by an earlier call with the same parameters):
-                                       skip the pack kernel */
+#define CSMPN_FLAG_WEIGHTS_PACKED 1u /* forward entry points: the workspace already holds this
+                                       CEMLP's packed weights (left there by an earlier forward with
+                                       the same parameters): skip the pack kernel. Accepted and
+                                       ignored by the backward entry points, which pack for their own
+                                       tile layout when it needs packed fragments at all. */
 
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
