@@ -72,6 +72,11 @@ class MVLinear(nn.Module):
 
     def forward(self, input):
         # y[b,o,...,d] = sum_i W[o,i,grade(d)] x[b,i,...,d]  (+ bias on the scalar blade)
+        if input.is_cuda and input.dim() == 3 and input.dtype == torch.float32 and self.algebra.dim <= 5:
+            # the HIP entry points (include/csmpn_hip.h: csmpn_mvlinear_forward / _backward)
+            return ops.mvlinear_apply(input, self.weight, self.bias, self.algebra.dim)
+        # host-side formulation for CPU tensors and inputs with extra middle dimensions (module
+        # construction / state_dict tests; no reference model calls MVLinear that way)
         w = self.weight
         if self.subspaces:
             w = w[..., _blade_grades(self.algebra, w.device)]          # [O, I, D]

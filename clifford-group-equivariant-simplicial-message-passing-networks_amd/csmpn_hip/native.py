@@ -24,6 +24,8 @@ EXPORTS = (
     "csmpn_cemlp_saved_floats_per_row",
     "csmpn_cemlp_forward",
     "csmpn_cemlp_backward",
+    "csmpn_mvlinear_forward",
+    "csmpn_mvlinear_backward",
     "csmpn_csr_build",
     "csmpn_egcl_edge_forward",
     "csmpn_egcl_edge_backward",
@@ -79,6 +81,8 @@ def _load():
     sig("csmpn_cemlp_saved_floats_per_row", sz, [C.c_int, bp, C.c_int])
     sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_mvlinear_forward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp])
+    sig("csmpn_mvlinear_backward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp])
     sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp])
     sig("csmpn_egcl_edge_forward", C.c_int,
         [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, sz, u32, vp])

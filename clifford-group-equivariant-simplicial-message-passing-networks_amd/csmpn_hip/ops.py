@@ -404,5 +404,48 @@ class _GpFn(torch.autograd.Function):
         return ga.sum_to_size(sa), gb.sum_to_size(sb), None
 
 
+# --------------------------------------------------------------------------------- standalone MVLinear
+
+
+class _MVLinearFn(torch.autograd.Function):
+    """y[b,o,d] = sum_i W[o,i,grade(d)] x[b,i,d] (+ bias on blade 0) through csmpn_mvlinear_*
+    (cegnn_utils.py:326-338), for the MVLinear calls outside a CEMLP."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, n):
+        _require_device(x, "MVLinear input")
+        x = x.contiguous()
+        w = weight.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        rows, I, D = x.shape
+        O = w.shape[0]
+        if D != (1 << n) or w.shape[1] != I:
+            raise RuntimeError(f"MVLinear: input {tuple(x.shape)} does not match weight {tuple(w.shape)} (n={n})")
+        y = torch.empty(rows, O, D, dtype=torch.float32, device=x.device)
+        check(native.lib().csmpn_mvlinear_forward(n, x.data_ptr(), w.data_ptr(), _ptr(b), rows, I, O,
+                                                  1 if w.dim() == 3 else 0, y.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(x, w)
+        ctx.n, ctx.has_bias = n, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        rows, I, D = x.shape
+        O = w.shape[0]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        gb = torch.zeros(1, O, 1, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(native.lib().csmpn_mvlinear_backward(ctx.n, x.data_ptr(), w.data_ptr(), gy.data_ptr(), rows, I, O,
+                                                   1 if w.dim() == 3 else 0, _ptr(gx), _ptr(gw), _ptr(gb),
+                                                   _stream(x.device)))
+        return gx, gw, gb, None
+
+
+def mvlinear_apply(x, weight, bias, n):
+    return _MVLinearFn.apply(x, weight, bias, int(n))
+
+
 def geometric_product_apply(a, b, metric):
     return _GpFn.apply(a, b, tuple(float(m) for m in metric))

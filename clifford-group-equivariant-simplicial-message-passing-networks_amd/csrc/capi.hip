@@ -497,6 +497,93 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     return CSMPN_OK;
 }
 
+// ----------------------------------------------------------------------------- standalone MVLinear
+// (cegnn_utils.py:287-338) for callers outside a CEMLP (projection heads, feature embeddings):
+//   y[b,o,d] = sum_i W[o,i,grade(d)] x[b,i,d]  (+ bias[o] on blade 0);  W [O,I,G] or [O,I].
+// HBM-bound ([rows, I, D] in, [rows, O, D] out); one thread per output element, blade index
+// fastest so that a wave reads / writes whole rows; the grade table depends on n only.
+struct MvLinDesc {
+    const float *x, *w, *b, *gy;
+    float *y, *gx, *gw, *gb;
+    long rows;
+    int I, O, D, G, sub;
+    unsigned char grade[32];
+};
+
+__global__ void mvlinear_fwd_kernel(const MvLinDesc P) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = P.rows * P.O * P.D;
+    if (e >= total) return;
+    const int d = (int)(e % P.D);
+    const int o = (int)((e / P.D) % P.O);
+    const long r = e / ((long)P.D * P.O);
+    const int g = P.sub ? P.grade[d] : 0, ws = P.sub ? P.G : 1;
+    const float* xr = P.x + r * P.I * P.D + d;
+    const float* wr = P.w + (long)o * P.I * ws + g;
+    float acc = (P.b && d == 0) ? P.b[o] : 0.f;
+    for (int i = 0; i < P.I; ++i) acc = fmaf(wr[i * ws], xr[(long)i * P.D], acc);
+    P.y[e] = acc;
+}
+
+// d/dx[b,i,d] = sum_o gy[b,o,d] W[o,i,grade(d)]
+__global__ void mvlinear_bwd_x_kernel(const MvLinDesc P) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = P.rows * P.I * P.D;
+    if (e >= total) return;
+    const int d = (int)(e % P.D);
+    const int i = (int)((e / P.D) % P.I);
+    const long r = e / ((long)P.D * P.I);
+    const int g = P.sub ? P.grade[d] : 0, ws = P.sub ? P.G : 1;
+    const float* gr = P.gy + r * P.O * P.D + d;
+    const float* wc = P.w + (long)i * ws + g;
+    float acc = 0.f;
+    for (int o = 0; o < P.O; ++o) acc = fmaf(wc[(long)o * P.I * ws], gr[(long)o * P.D], acc);
+    P.gx[e] = acc;
+}
+
+// d/dW[o,i,g] += sum_{rows, d in g} gy[b,o,d] x[b,i,d];  d/dbias[o] += sum_rows gy[b,o,0].
+// A workgroup takes a slab of rows; thread t owns weight elements t, t + 256, ... and walks the slab
+// (x / gy rows of the slab are L1/L2 hits after the first touch); one atomic per element and slab.
+constexpr int kMvLinSlab = 64;
+__global__ void mvlinear_bwd_w_kernel(const MvLinDesc P) {
+    const long r0 = (long)blockIdx.x * kMvLinSlab;
+    const long r1 = r0 + kMvLinSlab < P.rows ? r0 + kMvLinSlab : P.rows;
+    const int ws = P.sub ? P.G : 1;
+    const int nw = P.O * P.I * ws;
+    for (int e = threadIdx.x; e < nw + P.O; e += blockDim.x) {
+        float acc = 0.f;
+        if (e < nw) {
+            const int g = e % ws, i = (e / ws) % P.I, o = e / (ws * P.I);
+            for (long r = r0; r < r1; ++r) {
+                const float* gr = P.gy + (r * P.O + o) * P.D;
+                const float* xr = P.x + (r * P.I + i) * P.D;
+                for (int d = 0; d < P.D; ++d)
+                    if (!P.sub || P.grade[d] == g) acc = fmaf(gr[d], xr[d], acc);
+            }
+            atomicAdd(P.gw + e, acc);
+        } else if (P.gb) {
+            const int o = e - nw;
+            for (long r = r0; r < r1; ++r) acc += P.gy[(r * P.O + o) * P.D];
+            atomicAdd(P.gb + o, acc);
+        }
+    }
+}
+
+int mvlinear_desc(int n, long rows, int I, int O, int sub, MvLinDesc& P) {
+    if (n < 1 || n > 5) return fail(CSMPN_ERR_UNSUPPORTED, "MVLinear: n=%d not in 1..5", n);
+    if (I < 1 || O < 1 || rows < 0) return fail(CSMPN_ERR_INVALID, "MVLinear: bad sizes rows=%ld I=%d O=%d", rows, I, O);
+    memset(&P, 0, sizeof(P));
+    P.rows = rows; P.I = I; P.O = O; P.D = 1 << n; P.G = n + 1; P.sub = sub ? 1 : 0;
+    // blade order: by grade, then lexicographic (metric.py:18-29): the grade of index d is the
+    // grade whose cumulative binomial range contains d
+    int d = 0, c = 1;   // c = C(n, g)
+    for (int g = 0; g <= n; ++g) {
+        for (int k = 0; k < c; ++k) P.grade[d++] = (unsigned char)g;
+        c = c * (n - g) / (g + 1);
+    }
+    return CSMPN_OK;
+}
+
 // ----------------------------------------------------------------------------- CSR build kernels
 __global__ void csr_count_kernel(const int64_t* dst, long E, int* deg) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -698,6 +785,44 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream);
+}
+
+int csmpn_mvlinear_forward(int n, const float* x, const float* weight, const float* bias, int64_t rows,
+                           int32_t in_features, int32_t out_features, int32_t subspaces, float* y, void* stream) {
+    MvLinDesc P;
+    int rc = mvlinear_desc(n, (long)rows, in_features, out_features, subspaces, P);
+    if (rc) return rc;
+    if (rows == 0) return CSMPN_OK;
+    if (!x || !weight || !y) return fail(CSMPN_ERR_INVALID, "MVLinear: null pointer");
+    P.x = x; P.w = weight; P.b = bias; P.y = y;
+    const long total = (long)rows * out_features * P.D;
+    const unsigned block = 256, grid = (unsigned)((total + block - 1) / block);
+    hipLaunchKernelGGL(mvlinear_fwd_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
+    HIP_TRY(hipGetLastError());
+    return CSMPN_OK;
+}
+
+int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const float* gy, int64_t rows,
+                            int32_t in_features, int32_t out_features, int32_t subspaces, float* gx, float* g_weight,
+                            float* g_bias, void* stream) {
+    MvLinDesc P;
+    int rc = mvlinear_desc(n, (long)rows, in_features, out_features, subspaces, P);
+    if (rc) return rc;
+    if (rows == 0) return CSMPN_OK;
+    if (!x || !weight || !gy) return fail(CSMPN_ERR_INVALID, "MVLinear: null pointer");
+    P.x = x; P.w = weight; P.gy = gy; P.gx = gx; P.gw = g_weight; P.gb = g_bias;
+    const unsigned block = 256;
+    if (gx) {
+        const long total = (long)rows * in_features * P.D;
+        hipLaunchKernelGGL(mvlinear_bwd_x_kernel, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0,
+                           (hipStream_t)stream, P);
+    }
+    if (g_weight) {
+        const unsigned grid = (unsigned)((rows + kMvLinSlab - 1) / kMvLinSlab);
+        hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    return CSMPN_OK;
 }
 
 int csmpn_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* perm, int32_t* src_sorted,

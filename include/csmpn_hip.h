@@ -129,6 +129,18 @@ int csmpn_cemlp_backward(const float* metric_host, int n, const csmpn_block_para
                          const csmpn_block_grads* grads, int n_blocks, const float* x, const float* gy,
                          int64_t rows, float* gx, const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* Standalone MVLinear (csmpn/models/cegnn_utils.py:287-338; the callers outside a CEMLP: the
+ * projection heads hulls_cssmpnn.py:71-73 and the first stage of the simplex feature embeddings):
+ *   y[b,o,d] = sum_i W[o,i,grade(d)] x[b,i,d] (+ bias[o] on blade 0)
+ * weight is [O,I,G] (subspaces != 0) or [O,I]; bias [O] or NULL. The grade table depends on n only
+ * (blade order metric.py:18-29), so every metric with n <= 5 generators is served. Backward: gx
+ * [rows,I,D] overwritten (may be NULL), g_weight += d/dW (may be NULL), g_bias += d/dbias (may be NULL). */
+int csmpn_mvlinear_forward(int n, const float* x, const float* weight, const float* bias, int64_t rows,
+                           int32_t in_features, int32_t out_features, int32_t subspaces, float* y, void* stream);
+int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const float* gy, int64_t rows,
+                            int32_t in_features, int32_t out_features, int32_t subspaces, float* gx, float* g_weight,
+                            float* g_bias, void* stream);
+
 /* One-time per complex: sort the E directed adjacencies by target.
  * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
  * Outputs (device): perm[E] (sorted position -> original edge id), src_sorted[E],
