@@ -94,9 +94,12 @@ class CemlpBinding:
     def workspace(self, device) -> torch.Tensor:
         return torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=device)
 
-    def new_grads(self, params: Sequence[Optional[torch.Tensor]], device):
-        """One zeroed flat buffer for all parameter gradients (a single memset);
-        returns (flat, views) with views[i] shaped like params[i]."""
+    def grad_floats(self, params: Sequence[Optional[torch.Tensor]]) -> int:
+        """Floats of the flat gradient buffer new_grads() lays out for these parameters."""
+        self._layout(params)
+        return max(self._grad_layout[1], 1)
+
+    def _layout(self, params):
         if self._grad_layout is None:
             offs, total = [], 0
             for p in params:
@@ -106,8 +109,15 @@ class CemlpBinding:
                     offs.append((total, p.numel(), tuple(p.shape)))
                     total += (p.numel() + 3) // 4 * 4
             self._grad_layout = (offs, total)
+
+    def new_grads(self, params: Sequence[Optional[torch.Tensor]], device, flat=None):
+        """One zeroed flat buffer for all parameter gradients (a single memset; or the caller's
+        already zeroed `flat` of grad_floats() elements); returns (flat, views) with views[i]
+        shaped like params[i]."""
+        self._layout(params)
         offs, total = self._grad_layout
-        flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
+        if flat is None:
+            flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
         base = flat.data_ptr()
         views = []
         for k in range(self.nblk):
@@ -239,12 +249,14 @@ class HipBackend:
         return get_csr(edge_index, n_nodes)
 
     @staticmethod
-    def edge_forward(spec, csr, h, edge_attr, pe, save=True):
-        """Returns (agg, state); state = (workspace with packed weights, saved block inputs)."""
+    def edge_forward(spec, csr, h, edge_attr, pe, save=True, agg=None):
+        """Returns (agg, state); state = (workspace with packed weights, saved block inputs).
+        agg: optional zeroed [N, O, D] output buffer."""
         e = spec.edge
         e.bind(pe)
         N, D = h.shape[0], e.D
-        agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
+        if agg is None:
+            agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
         ws = e.workspace(h.device)
         saved = e.new_saved(csr.n_edges, h.device) if save else None
         check(native.lib().csmpn_egcl_edge_forward(
@@ -268,12 +280,13 @@ class HipBackend:
         return out, (ws, saved)
 
     @staticmethod
-    def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None):
-        """state: the workspace node_forward returned (its packed weights are reused)."""
+    def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None, gflat=None):
+        """state: the workspace node_forward returned (its packed weights are reused);
+        gflat: optional zeroed flat gradient buffer (CemlpBinding.grad_floats elements)."""
         nd = spec.node
         nd.bind(pn)
         N, D, dev = h.shape[0], nd.D, h.device
-        _flat, views = nd.new_grads(pn, dev)
+        _flat, views = nd.new_grads(pn, dev, gflat)
         gh = torch.empty_like(h)
         g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
         g_na = torch.empty_like(node_attr) if (node_attr is not None and want_gna) else None
@@ -286,12 +299,12 @@ class HipBackend:
         return gh, g_agg, g_na, views
 
     @staticmethod
-    def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None):
-        """gh is accumulated in place (+= scatter of +-d/d(h_i - h_j))."""
+    def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None, gflat=None):
+        """gh is accumulated in place (+= scatter of +-d/d(h_i - h_j)); gflat as in node_backward."""
         e = spec.edge
         e.bind(pe)
         N, dev = h.shape[0], h.device
-        _flat, views = e.new_grads(pe, dev)
+        _flat, views = e.new_grads(pe, dev, gflat)
         g_ea = torch.empty_like(edge_attr) if (edge_attr is not None and want_gea) else None
         ws, saved = state if state is not None else (e.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
@@ -328,7 +341,15 @@ class _EgclFn(torch.autograd.Function):
             node_attr = node_attr.contiguous()
         ne = spec.edge.nblk * NP
         pe, pn = params[:ne], params[ne:]
-        agg, st_e = HipBackend.edge_forward(spec, csr, h, edge_attr, pe)
+        # one memset for everything that must start from zero: the aggregate and, when a backward
+        # will follow, both models' flat gradient buffers
+        spec.edge.bind(pe); spec.node.bind(pn)
+        n_agg = h.shape[0] * spec.O * spec.edge.D
+        n_ge, n_gn = (spec.edge.grad_floats(pe), spec.node.grad_floats(pn)) if any(ctx.needs_input_grad) else (0, 0)
+        zeros = torch.zeros(n_agg + n_ge + n_gn, dtype=torch.float32, device=h.device)
+        agg = zeros[:n_agg].view(h.shape[0], spec.O, spec.edge.D)
+        ctx.gflats = (zeros[n_agg:n_agg + n_ge], zeros[n_agg + n_ge:]) if n_ge else None
+        agg, st_e = HipBackend.edge_forward(spec, csr, h, edge_attr, pe, agg=agg)
         out, st_n = HipBackend.node_forward(spec, csr.deg, h, agg, node_attr, pn)
         ctx.spec, ctx.csr, ctx.st_e, ctx.st_n = spec, csr, st_e, st_n
         ctx.has_ea, ctx.has_na = edge_attr is not None, node_attr is not None
@@ -357,10 +378,12 @@ class _EgclFn(torch.autograd.Function):
         ne = spec.edge.nblk * NP
         pe, pn = params[:ne], params[ne:]
         gout = gout.contiguous()
+        gfe, gfn = ctx.gflats if ctx.gflats is not None else (None, None)
+        ctx.gflats = None   # zeroed once: a second backward through the same graph allocates afresh
         gh, g_agg, g_na, views_n = HipBackend.node_backward(spec, csr.deg, h, agg, node_attr, pn, gout,
-                                                            ctx.needs_input_grad[2], ctx.st_n)
+                                                            ctx.needs_input_grad[2], ctx.st_n, gfn)
         g_ea, views_e = HipBackend.edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, ctx.needs_input_grad[1],
-                                                 ctx.st_e)
+                                                 ctx.st_e, gfe)
         return (gh, g_ea, g_na, None, None, *views_e, *views_n)
 
 
