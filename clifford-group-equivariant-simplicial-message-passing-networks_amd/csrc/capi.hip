@@ -308,10 +308,11 @@ int mirror_total(int G, int P, const csmpn_block_params* blocks, int nblk) {
 // count, so a forward and the backward that reads its saved block inputs always agree.
 bool decide_ps(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
     if (!has_ps(id)) return false;
-    // Opt-in (CSMPN_FORCE_PS=1): measured 15-20 % slower than the 32-row layout on S1 despite
-    // twice the resident waves (negative results).
+    // Default: on for D = 32 (n = 5: half the registers per tensor and every lane column in use
+    // instead of 8 of 16 - S3 runs 1.9x faster), off for Cl(3,0), where it measured 15-20 % slower
+    // than the 32-row layout. CSMPN_FORCE_PS=0|1 overrides.
     const char* f = getenv("CSMPN_FORCE_PS");
-    if (!f || atoi(f) == 0) return false;
+    if (f ? atoi(f) == 0 : n < 5) return false;
     for (int k = 0; k < nblk; ++k) if (blocks[k].out_features > 8) return false;
     const int D = 1 << n, G = n + 1;
     const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
@@ -321,7 +322,8 @@ bool decide_ps(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
     const TileLayout Lf = tile_layout(D, 1, blocks, nblk, false, 8 * D, false, true);
     const Choice cb = choose_variant(1, (size_t)Lb.total * 4, mirror, wst, true, true);
     const Choice cf = choose_variant(1, (size_t)Lf.total * 4, 0, wst, false, true);
-    return cb.var == VAR_WAVE && cf.var == VAR_WAVE && cb.rt * cb.wgs >= 4 && cf.rt * cf.wgs >= 4;
+    const int need = n >= 5 ? 1 : 4;   // D = 32: one 16-row tile per CU is all the LDS holds in any layout
+    return cb.var == VAR_WAVE && cf.var == VAR_WAVE && cb.rt * cb.wgs >= need && cf.rt * cf.wgs >= need;
 }
 
 int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,

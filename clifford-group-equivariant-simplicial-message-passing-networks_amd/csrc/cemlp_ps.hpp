@@ -759,7 +759,7 @@ CSMPN_DEV void ps_block_backward(const DevBlock& B, const PSLaneParams<ALG>& lp,
 // Forward: 512 threads per workgroup (VGPRs bounded to 128: 4 waves per SIMD with two
 // workgroups per CU); backward: 512 threads (256 VGPRs: 2 waves per SIMD).
 template <class ALG, int MODE, bool BWD>
-__global__ void __launch_bounds__(256, BWD ? 1 : 3) cemlp_ps_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(256, (BWD || ALG::n >= 5) ? 1 : 3) cemlp_ps_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
