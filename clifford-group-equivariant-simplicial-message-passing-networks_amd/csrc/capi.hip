@@ -173,7 +173,7 @@ struct Plan {
 // floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
 struct TileLayout { int off_in, off_p0, off_p1, off_z, off_g, off_red, off_idx, total; };
 TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk, bool bwd, int stage_rowlen,
-                       bool use_saved = false, bool ps = false) {
+                       bool use_saved = false, bool ps = false, bool share_inz = false) {
     int maxO = 0, maxCPo = 0;
     for (int k = 0; k < nblk; ++k) {
         maxO = blocks[k].out_features > maxO ? blocks[k].out_features : maxO;
@@ -185,7 +185,7 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
     const int sz_o = maxCPo * CS;
     // backward with saved block inputs: ONE input buffer serves every block in turn
     const bool single_in = bwd && use_saved && nblk > 1;
-    if (single_in && sz_o > sz_in) sz_in = sz_o;
+    if ((single_in || share_inz) && sz_o > sz_in) sz_in = sz_o;
     TileLayout L;
     int off = 0;
     if (!bwd) {
@@ -210,7 +210,8 @@ TileLayout tile_layout(int D, int H, const csmpn_block_params* blocks, int nblk,
         L.off_in = off; off += sz_in;
         L.off_p0 = off; off += (nblk >= 2 && !single_in) ? sz_o : 0;
         L.off_p1 = off; off += (nblk >= 3 && !single_in) ? sz_o : 0;
-        L.off_z = off; off += sz_o;
+        if (share_inz) L.off_z = L.off_in;   // z aliases the input buffer (sz_in >= sz_o, checked by the caller)
+        else { L.off_z = off; off += sz_o; }
         L.off_g = off;
         int sz_g = sz_o;
         if (stage_rowlen > 0 && R * stage_rowlen > sz_g) sz_g = rup(R * stage_rowlen, 4);
@@ -427,13 +428,27 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     plan.pack_f4 = cursor;
 
     // buffers of one row tile (floats)
-    const TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps);
+    TileLayout L = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps);
+    // choose the storage variant, row tiles per workgroup and workgroups per CU
+    Choice ch = choose_variant(MT, (size_t)L.total * 4, bwd ? (size_t)mirror * 4 : 0, (size_t)wstore * 4, bwd, ps);
+    // Backward, when LDS (not registers) limits the resident waves: let z alias the input buffer and
+    // stage the input tile a second time for the MVLinear weight gradient, if that buys a row tile
+    // per CU (S2: 3 -> 4 waves per CU) or a better storage variant. Needs every block's input to be
+    // re-stageable from memory: a single block, or saved block inputs.
+    C.share_inz = 0;
+    static const bool allow_share = !(getenv("CSMPN_NO_SHARE") && atoi(getenv("CSMPN_NO_SHARE")));
+    if (bwd && !ps && H == 1 && allow_share && (use_saved || nblk == 1)) {
+        const TileLayout Ls = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps, true);
+        const Choice cs = choose_variant(MT, (size_t)Ls.total * 4, (size_t)mirror * 4, (size_t)wstore * 4, bwd, ps);
+        // resident waves per CU: the backward kernels hold ~500 VGPRs, one wave per SIMD at most
+        auto resident = [&](const Choice& c) { const int w = c.rt * c.wgs * MT; return w < 4 ? w : 4; };
+        if (cs.var < ch.var || (cs.var == ch.var && resident(cs) > resident(ch))) {
+            L = Ls; ch = cs; C.share_inz = 1;
+        }
+    }
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
     C.off_red = L.off_red; C.off_idx = L.off_idx; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
-
-    // choose the storage variant, row tiles per workgroup and workgroups per CU
-    const Choice ch = choose_variant(MT, tile_bytes, bwd ? (size_t)mirror * 4 : 0, (size_t)wstore * 4, bwd, ps);
     if (ps && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: parity-split plan without the single-wave variant");
     if (H == 2 && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: H=2 without the single-wave variant");
     C.RT = ch.rt;
@@ -491,8 +506,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
     static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
-                mode, (int)bwd, plan.var, (int)plan.ps, plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
+        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d share=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
+                mode, (int)bwd, plan.var, (int)plan.ps, Cd.share_inz, plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
                 Cd.tile_floats, Cd.mirror_floats, io.rows);
     if (plan.ps) HIP_TRY(launch_cemlp_ps(id, mode, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
     else HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));

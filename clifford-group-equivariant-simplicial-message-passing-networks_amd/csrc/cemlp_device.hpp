@@ -73,7 +73,9 @@ struct DevCemlp {
     int tile_floats;     // floats per row tile
     int mirror_floats;   // LDS floats of the gradient mirror (0 if not used)
     int wstore_floats;   // LDS floats of the weight store (VAR_WAVE, else 0)
-    int pad_;
+    int share_inz;       // backward: the z buffer aliases the input buffer; the input tile is staged
+                         // again in front of the MVLinear weight gradient (one more row tile per CU
+                         // where LDS, not registers, limits the resident waves)
     float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
     DevBlock b[4];
 };
@@ -630,7 +632,7 @@ CSMPN_DEV MirrorOff mirror_offsets(int I, int O, int G, int P, bool w1_sub) {
 template <class ALG, int H, int VAR, bool SPEC = true>
 CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const float* xin, float* zbuf,
                              float* red, const float* wstore, int MT, int mt, const Geo<ALG, H>& ge,
-                             FwdState<ALG>& S, f4 (&out)[ALG::D]) {
+                             FwdState<ALG>& S, f4 (&out)[ALG::D], bool alias_in_z = false) {
     using GE = Geo<ALG, H>;
     static_assert(H == 1 || !kVarBarrier<VAR>, "multi-wave row tiles use H = 1");
     constexpr int D = ALG::D, G = ALG::G, NW = GE::NW;
@@ -670,7 +672,7 @@ CSMPN_DEV void block_forward(const DevBlock& B, const LaneParams<ALG>& lp, const
     });
     // single-wave forward tiles keep z in the buffer the MVLinear just read (host layout):
     // nothing may move the stores above those reads
-    if constexpr (VAR == VAR_WAVE) tile_sync<VAR>();
+    if (VAR == VAR_WAVE || alias_in_z) tile_sync<VAR>();
     store_tile<ALG, H>(z, zbuf, B.CPo, mt, ge);
     tile_sync<VAR>();
     ge.stamp(4);
@@ -742,7 +744,7 @@ template <class ALG, int H, int VAR>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
                               float* red, float* mirror, const float* wstore, int MT, int mt,
-                              const Geo<ALG, H>& ge, f4 (&gy)[ALG::D]) {
+                              const Geo<ALG, H>& ge, f4 (&gy)[ALG::D], bool defer_w1 = false) {
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P, NW = GE::NW;
     const int c = NW * mt + ge.cn;
@@ -918,9 +920,22 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
     // ---- MVLinear weight gradient; gy tile to LDS for the transposed MVLinear
     tile_sync<VAR>();   // all reads of gbuf (GR) done
     store_tile<ALG, H>(gy, gbuf, B.CPo, mt, ge);
-    if (tile_active) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
+    // defer_w1: the input tile is gone (its buffer holds z): the caller stages it again and runs
+    // block_w1_grad itself
+    if (tile_active && !defer_w1) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
     tile_sync<VAR>();
     ge.stamp(16);
+}
+
+// the MVLinear weight gradient of block_backward, for callers that deferred it (defer_w1)
+template <class ALG, int H, int VAR>
+CSMPN_DEV void block_w1_grad(const DevBlock& B, const f4 (&gy)[ALG::D], const float* xin, float* mirror, int mt,
+                             const Geo<ALG, H>& ge) {
+    constexpr int G = ALG::G, NW = Geo<ALG, H>::NW;
+    constexpr bool in_lds = kVarMirror<VAR>;
+    const MirrorOff mo = mirror_offsets(B.I, B.O, G, ALG::P, B.w1_sub != 0);
+    float* d_W1 = in_lds ? mirror + B.lds_goff + mo.W1 : B.gW1;
+    if (NW * mt < B.O) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
 }
 
 // flush one block's LDS gradient mirror into the global reference-layout accumulators

@@ -533,9 +533,19 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 {
                     FwdState<ALG> S;
                     f4 unused[D];
-                    block_forward<ALG, H, VAR, BWD>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused);
+                    // 16-row tiles only: the 32-row kernels are register-bound (4 waves per CU fit their LDS)
+                    const bool share = H == 1 && C.share_inz != 0;
+                    block_forward<ALG, H, VAR, BWD>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused, share);
                     if constexpr (PARK) { tile_sync<VAR>(); unpark<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
-                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy);
+                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy, share);
+                    if (share) {
+                        // z lived in the input buffer: bring the block's input tile back for the MVLinear weight gradient
+                        if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
+                        else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
+                        tile_sync<VAR>();
+                        block_w1_grad<ALG, H, VAR>(B, gy, buf_in, mirror, mt, ge);
+                        tile_sync<VAR>();
+                    }
                 }
                 // transposed MVLinear: gx[i] = sum_o W1[o][i][g] gy[o]   (A = gy tile in LDS)
                 const WOff wo = wstore_offsets(B.O, B.CPi, B.CPo, G, ALG::P, B.w1_sub != 0);
