@@ -402,3 +402,14 @@ def test_graphed_sharded_step_matches_autograd(pkg):
     for p, g in zip(flat, ge + gn):
         if p is not None:
             assert rel(g, by_id[id(p)]) < 2e-5
+
+
+@pytest.mark.parametrize("force,metric,C", [("1", [1.0, 1.0, 1.0], 8), ("1", [1.0, 1.0, 1.0], 5),
+                                            ("0", [1.0, 1.0, 1.0, 1.0, 1.0], 8)])
+def test_layout_overrides(pkg, monkeypatch, force, metric, C):
+    """Both tile layouts of the narrow odd-n configurations stay covered whatever the default is:
+    the parity-split kernels for Cl(3,0) (opt-in) and the 16-row layout for Cl(5,0) (opt-out).
+    The library reads CSMPN_FORCE_PS at every launch plan."""
+    monkeypatch.setenv("CSMPN_FORCE_PS", force)
+    _oracle_egcl_case(metric, 203, 2501, C, C, "mean", seed=11)
+    _oracle_egcl_case(metric, 64, 333, C, C, "sum", seed=12, residual=False)
