@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--workload", default="S1", choices=sorted(WORKLOADS))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--segments", action="store_true",
                     help="run the N>1 launch path (graph segments + eager collectives) on one GPU too")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work")
@@ -142,11 +143,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer
+    # GPUs than ranks (--dist-backend gloo: RCCL refuses two ranks on one device)
+    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
     from csmpn_hip import ops, sharded

@@ -53,6 +53,18 @@ def _worker(rank, world, port, q):
         res = {"y": rel(y, y2), "deg": int((plan.deg.long() - torch.bincount(ei[1], minlength=N)).abs().max())}
         for i, (a, b) in enumerate(zip(gs, g2)):
             res[f"g{i}"] = rel(a, b)
+        # the fixed-buffer step (compute in two HIP graphs, the collectives eager between them)
+        st = sharded.GraphedShardedStep(sl, plan, h, ea[lo:hi].contiguous(), na, gout)
+        for _ in range(2):
+            st.run()
+        torch.cuda.synchronize()
+        out, gh, ge, gn = st.results()
+        res["graph.y"], res["graph.gh"] = rel(out, y2.detach()), rel(gh, g2[0])
+        flat = layer.edge_model.flat_params() + layer.node_model.flat_params()
+        by_id = {id(p): g for p, g in zip(params, g2[1:])}
+        for j, (p, g) in enumerate(zip(flat, ge + gn)):
+            if p is not None:
+                res[f"graph.g{j}"] = rel(g, by_id[id(p)])
         q.put((rank, res))
     finally:
         dist.destroy_process_group()
