@@ -413,3 +413,37 @@ def test_layout_overrides(pkg, monkeypatch, force, metric, C):
     monkeypatch.setenv("CSMPN_FORCE_PS", force)
     _oracle_egcl_case(metric, 203, 2501, C, C, "mean", seed=11)
     _oracle_egcl_case(metric, 64, 333, C, C, "sum", seed=12, residual=False)
+
+
+@pytest.mark.parametrize("in_f,C,nl", [(40, 16, 1), (40, 16, 2), (22, 16, 2)])
+def test_cemlp_shared_input_buffer(pkg, in_f, C, nl):
+    """Shapes whose backward fits fewer than four row tiles per CU: `z` aliases the input buffer and
+    the input tile is staged a second time for the MVLinear weight gradient (single block: from the
+    caller's x; two blocks: from x and from the saved block input). Against the float64 oracle."""
+    metric = [1.0, 1.0, 1.0]
+    oa, o32 = O.Algebra(metric, torch.float64), O.Algebra(metric, torch.float32)
+    gen = torch.Generator().manual_seed(21)
+    p = O.init_cemlp_params(o32, in_f, C, C, n_layers=nl, gen=gen, randomize=True)
+    m = pkg.CEMLP(pkg.CliffordAlgebra(tuple(metric)), in_f, C, C, n_layers=nl)
+    sd = m.state_dict()
+    for k, v in p.items():
+        sd[k] = v
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev())
+    x = torch.randn(777, in_f, 8, generator=gen)
+    gout = torch.randn(777, C, 8, generator=gen)
+    xd = x.to(dev()).requires_grad_(True)
+    y = m(xd)
+    (y * gout.to(dev())).sum().backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    x64 = x.double().requires_grad_(True)
+    y64 = O.cemlp(oa, x64, p64)
+    (y64 * gout.double()).sum().backward()
+    p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x32 = x.clone().requires_grad_(True)
+    y32 = O.cemlp(o32, x32, p32)
+    (y32 * gout).sum().backward()
+    check("y", y.detach().cpu().numpy(), y64.detach().numpy(), y32.detach().numpy())
+    check("gx", xd.grad.cpu().numpy(), x64.grad.numpy(), x32.grad.numpy())
+    for k, prm in m.named_parameters():
+        check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy())
