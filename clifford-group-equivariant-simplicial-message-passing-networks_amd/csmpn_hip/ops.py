@@ -209,6 +209,16 @@ class Csr:
                                            self._scratch.data_ptr(), _stream(dev)))
 
 
+class CsrSlice:
+    """Rows [lo, hi) of a target-sorted adjacency (views; for launching the edge forward in pieces)."""
+
+    __slots__ = ("perm", "src", "dst", "n_edges", "n_nodes")
+
+    def __init__(self, csr: Csr, lo: int, hi: int):
+        self.perm, self.src, self.dst = csr.perm[lo:hi], csr.src[lo:hi], csr.dst[lo:hi]
+        self.n_edges, self.n_nodes = hi - lo, csr.n_nodes
+
+
 def get_csr(edge_index: torch.Tensor, n_nodes: int) -> Csr:
     """CSR cached on the edge_index tensor object itself (complexes are static:
     every layer of a model and every epoch pass the same tensor)."""
@@ -249,16 +259,18 @@ class HipBackend:
         return get_csr(edge_index, n_nodes)
 
     @staticmethod
-    def edge_forward(spec, csr, h, edge_attr, pe, save=True, agg=None):
+    def edge_forward(spec, csr, h, edge_attr, pe, save=True, agg=None, saved=None):
         """Returns (agg, state); state = (workspace with packed weights, saved block inputs).
-        agg: optional zeroed [N, O, D] output buffer."""
+        agg: optional [N, O, D] buffer to accumulate into (zeroed by the caller); saved: optional
+        buffer for the saved block inputs of these csr.n_edges rows."""
         e = spec.edge
         e.bind(pe)
         N, D = h.shape[0], e.D
         if agg is None:
             agg = torch.zeros(N, spec.O, D, dtype=torch.float32, device=h.device)
         ws = e.workspace(h.device)
-        saved = e.new_saved(csr.n_edges, h.device) if save else None
+        if saved is None and save:
+            saved = e.new_saved(csr.n_edges, h.device)
         check(native.lib().csmpn_egcl_edge_forward(
             e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
             csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(),

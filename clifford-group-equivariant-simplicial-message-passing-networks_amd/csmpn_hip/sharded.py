@@ -147,8 +147,36 @@ class GraphedShardedStep:
         self._multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         h_, ea, na, pe, pn = self.h, self.ea, self.na, self.pe, self.pn
 
+        # N > 1: the edge forward runs as two launches over the two halves of the target-sorted
+        # shard (targets < N/2 | >= N/2), so that the all-reduce of the first half of the aggregate
+        # travels while the second half is still being computed. Needs the saved block inputs to be
+        # one [rows, O, D] array (two-block edge model) and the default backend.
+        import os
+        self._split = None
+        if (self._multi and be is ops.HipBackend and spec.edge.nblk == 2
+                and os.environ.get("CSMPN_SPLIT_FWD", "1") != "0"):
+            n_half = plan.n_nodes // 2
+            e1 = int(plan.csr.row_ptr[n_half].item())
+            if 0 < e1 < plan.csr.n_edges:
+                self._split = (n_half, e1)
+
         def part1():
             return be.edge_forward(spec, plan.csr, h_, ea, pe)
+
+        def part1_lo():
+            n_half, e1 = self._split
+            spec.edge.bind(pe)
+            agg = torch.zeros(h_.shape[0], spec.O, spec.edge.D, dtype=torch.float32, device=h_.device)
+            saved = spec.edge.new_saved(plan.csr.n_edges, h_.device)
+            per_row = saved.numel() // plan.csr.n_edges
+            _, (ws, _s) = be.edge_forward(spec, ops.CsrSlice(plan.csr, 0, e1), h_, ea, pe, agg=agg,
+                                          saved=saved[:e1 * per_row])
+            return agg, (ws, saved), per_row
+
+        def part1_hi(agg, saved, per_row):
+            n_half, e1 = self._split
+            be.edge_forward(spec, ops.CsrSlice(plan.csr, e1, plan.csr.n_edges), h_, ea, pe, agg=agg,
+                            saved=saved[e1 * per_row:])
 
         def part2(agg, st_e):
             out, st_n = be.node_forward(spec, plan.deg, h_, agg, na, pn)
@@ -162,15 +190,27 @@ class GraphedShardedStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            agg, st_e = part1()
+            if self._split:
+                agg, st_e, per_row = part1_lo()
+                part1_hi(agg, st_e[1], per_row)
+            else:
+                agg, st_e = part1()
             part2(agg, st_e)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
         self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread-local capture mode: the process group's watchdog thread polls events while we capture
+        self.g1b = None
         with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
-            self.agg, self._st_e = part1()
+            if self._split:
+                self.agg, self._st_e, per_row = part1_lo()
+            else:
+                self.agg, self._st_e = part1()
+        if self._split:
+            self.g1b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g1b, pool=self.g1.pool(), capture_error_mode="thread_local"):
+                part1_hi(self.agg, self._st_e[1], per_row)
         with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
             self.out, self.gh_node, self.packed, views_e, self.views_n = part2(self.agg, self._st_e)
         self._edge_shapes = [None if v is None else tuple(v.shape) for v in views_e]
@@ -178,7 +218,14 @@ class GraphedShardedStep:
 
     def run(self):
         self.g1.replay()
-        if self._multi:
+        if self._split:
+            n_half = self._split[0]
+            w_lo = dist.all_reduce(self.agg[:n_half], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.g1b.replay()   # writes rows >= n_half only
+            w_hi = dist.all_reduce(self.agg[n_half:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w_lo.wait()
+            w_hi.wait()
+        elif self._multi:
             dist.all_reduce(self.agg, op=dist.ReduceOp.SUM, group=self.group)
         self.g2.replay()
         if self._multi:
