@@ -447,3 +447,64 @@ def test_cemlp_shared_input_buffer(pkg, in_f, C, nl):
     check("gx", xd.grad.cpu().numpy(), x64.grad.numpy(), x32.grad.numpy())
     for k, prm in m.named_parameters():
         check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy())
+
+
+def _cemlp_case(pkg, metric, in_f, hid, out_f, nl, rows, seed, slack=4.0):
+    oa, o32 = O.Algebra(metric, torch.float64), O.Algebra(metric, torch.float32)
+    gen = torch.Generator().manual_seed(seed)
+    D = 1 << len(metric)
+    p = O.init_cemlp_params(o32, in_f, hid, out_f, n_layers=nl, gen=gen, randomize=True)
+    m = pkg.CEMLP(pkg.CliffordAlgebra(tuple(metric)), in_f, hid, out_f, n_layers=nl)
+    sd = m.state_dict()
+    for k, v in p.items():
+        sd[k] = v
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev())
+    x = torch.randn(rows, in_f, D, generator=gen)
+    gout = torch.randn(rows, out_f, D, generator=gen)
+    xd = x.to(dev()).requires_grad_(True)
+    y = m(xd)
+    (y * gout.to(dev())).sum().backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
+    x64 = x.double().requires_grad_(True)
+    (O.cemlp(oa, x64, p64) * gout.double()).sum().backward()
+    p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x32 = x.clone().requires_grad_(True)
+    y32 = O.cemlp(o32, x32, p32)
+    (y32 * gout).sum().backward()
+    y64 = O.cemlp(oa, x64.detach(), {k: v.detach() for k, v in p64.items()})
+    tag = f"in{in_f}_h{hid}_o{out_f}_nl{nl}_r{rows}"
+    check(tag + ".y", y.detach().cpu().numpy(), y64.numpy(), y32.detach().numpy(), slack=slack)
+    check(tag + ".gx", xd.grad.cpu().numpy(), x64.grad.numpy(), x32.grad.numpy(), slack=slack)
+    for k, prm in m.named_parameters():
+        check(f"{tag}.g.{k}", prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy(), slack=slack)
+
+
+def test_cemlp_shape_sweep(pkg):
+    """Seeded sweep over channel counts that are not multiples of 4 / 8 / 16, 1- and 2-block CEMLPs and
+    ragged row counts (partial tiles, fewer rows than a tile), Cl(3,0) and Cl(2,0): every k-block
+    size of the MFMA loops (4, 8, 12, 16 valid channels) and both staging paths get exercised."""
+    rng = np.random.default_rng(5)
+    for case in range(28):
+        metric = [1.0, 1.0, 1.0] if case % 4 else [1.0, 1.0]
+        # widths >= 2: a single output channel makes MVLayerNorm a pure normalisation (y = a x / |x|),
+        # whose small-parameter gradients cancel to rounding noise in every float32 implementation
+        in_f, hid, out_f = (int(rng.integers(1, 21)), int(rng.integers(2, 14)), int(rng.integers(2, 14)))
+        nl = int(rng.integers(1, 3))
+        rows = int(rng.choice([1, 5, 16, 17, 31, 33, 100, 257]))
+        _cemlp_case(pkg, metric, in_f, hid, out_f, nl, rows, seed=100 + case)
+
+
+def test_egcl_shape_sweep(pkg):
+    """Seeded sweep of the whole layer over widths that are not tile multiples, tiny and ragged
+    complexes (fewer edges than a tile, isolated nodes), both aggregations."""
+    rng = np.random.default_rng(9)
+    for case in range(12):
+        C = int(rng.choice([2, 3, 5, 6, 7, 9, 11, 12]))
+        hidden = int(rng.choice([2, 4, 7, 8, 10]))
+        # (a single node with hundreds of self loops makes d/dh an exact cancellation of +g and -g
+        # atomics: order-dependent rounding residue relative to a zero sum - not swept here)
+        N = int(rng.choice([3, 17, 50, 130]))
+        E = int(rng.choice([1, 7, 31, 33, 200, 1000]))
+        _oracle_egcl_case([1.0, 1.0, 1.0], N, E, C, hidden, "mean" if case % 2 else "sum", seed=300 + case,
+                          residual=bool(case % 3))
