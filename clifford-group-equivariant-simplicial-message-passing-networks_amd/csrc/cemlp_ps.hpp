@@ -95,8 +95,38 @@ constexpr PSTab<ALG> make_ps_tab() {
     return t;
 }
 
+// compile-time self-check of the tables: every path class maps to four existing reference paths,
+// the Hodge pairing is a bijection between even and odd blades, classes tile the slots, and the
+// pseudoscalar is central with I^2 = +-1 (what the two-product form of the geometric product needs)
+template <class ALG>
+constexpr bool ps_tab_ok() {
+    constexpr PSTab<ALG> t = make_ps_tab<ALG>();
+    constexpr int D = ALG::D, DL = D / 2, GC = (ALG::n + 1) / 2;
+    if (ALG::n % 2 == 0) return false;
+    bool seen[D] = {};
+    for (int s = 0; s < DL; ++s) {
+        if (t.par[t.ev[s]] != 0 || t.par[t.od[s]] != 1) return false;
+        if (t.slot[t.ev[s]] != s || t.slot[t.od[s]] != s) return false;
+        if (seen[t.ev[s]] || seen[t.od[s]]) return false;
+        seen[t.ev[s]] = seen[t.od[s]] = true;
+        if (t.eps[s] != 1 && t.eps[s] != -1) return false;
+        if (ALG::t.bo.grade[t.od[s]] != ALG::n - ALG::t.bo.grade[t.ev[s]]) return false;
+    }
+    if (t.I2 != 1 && t.I2 != -1) return false;
+    const int I = ALG::t.bo.index[D - 1];
+    for (int d = 0; d < D; ++d)   // I commutes with every blade
+        if (ALG::t.sign[d][I] != ALG::t.sign[I][d]) return false;
+    if (t.cstart[0] != 0 || t.cstart[GC] != DL) return false;
+    for (int q = 0; q < t.nq; ++q)
+        for (int s = 0; s < 2; ++s)
+            for (int k = 0; k < 2; ++k)
+                if (t.pid[s][k][q] < 0 || t.pid[s][k][q] >= ALG::P) return false;
+    return 4 * t.nq == ALG::P;   // the four products of the path classes enumerate all reference paths
+}
+
 template <class ALG>
 struct PS {
+    static_assert(ps_tab_ok<ALG>(), "parity-split tables are inconsistent for this algebra");
     static constexpr PSTab<ALG> t = make_ps_tab<ALG>();
     static constexpr int N = ALG::n, D = ALG::D, DL = D / 2, GC = (N + 1) / 2, G = ALG::G, QP = t.nq;
     static constexpr int R = 16, NW = 8, CS = R * D + 4;
