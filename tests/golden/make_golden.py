@@ -137,80 +137,101 @@ def make_layers(name, metric):
     np.savez_compressed(os.path.join(HERE, f"layers_{name}.npz"), **out)
 
 
+def _load_f32_params(layer64, layer32):
+    """The float64 layer gets the float32 layer's parameters (cast), so that both fixture runs
+    describe the SAME function; the algebra buffers keep the float64 layer's own values."""
+    sd = layer64.state_dict()
+    for k, v in layer32.state_dict().items():
+        if ".algebra." in k or k.startswith("algebra."):
+            continue
+        sd[k] = v.detach().to(torch.float64)
+    layer64.load_state_dict(sd, strict=True)
+
+
 def make_egcl(name, metric):
     out = {}
-    for dt_name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
-        torch.set_default_dtype(dtype)
-        gen = torch.Generator().manual_seed(37)
-        torch.manual_seed(37)
-        alg = CliffordAlgebra(metric)
-        D = alg.n_blades
-        N, E, C, T = 12, 40, 4, 3
-        ei = torch.randint(0, N - 1, (2, E), generator=gen)  # node N-1 is isolated
-        ei[:, 5] = ei[:, 4]            # duplicate edge
-        ei[:, 9] = ei[:, 4]            # triplicate
-        ei[1, 12] = ei[0, 12]          # self loop
-        ei[1, 20:28] = 3               # high in-degree node
-        types = torch.randint(0, T, (N,), generator=gen)
-        node_attr0 = alg.embed_grade(torch.nn.functional.one_hot(types, T).to(dtype)[..., None], 0)
-        h0 = torch.randn(N, C, D, generator=gen, dtype=torch.float32).to(dtype)
-        for aggr in ("sum", "mean"):
-            for residual in (True, False):
-                for attr_grad in (False, True):
-                    if attr_grad and not residual:
-                        continue
-                    tag = f"{dt_name}/{aggr}_res{int(residual)}_ag{int(attr_grad)}"
-                    g2 = torch.Generator().manual_seed(41)
-                    torch.manual_seed(41)
-                    layer = R.EGCL(alg, C, C, C, edge_attr_features=2 * T, node_attr_features=T,
-                                   residual=residual, aggr=aggr)
-                    randomize_(layer, g2)
-                    h = h0.clone().requires_grad_(True)
-                    if attr_grad:
-                        node_attr = (node_attr0 + 0.1 * torch.randn(node_attr0.shape, generator=g2,
-                                     dtype=torch.float32).to(dtype)).requires_grad_(True)
-                        edge_attr = torch.randn(E, 2 * T, D, generator=g2, dtype=torch.float32).to(dtype)
-                        edge_attr.requires_grad_(True)
-                    else:
-                        node_attr = node_attr0.clone()
-                        edge_attr = torch.cat([node_attr[ei[0]], node_attr[ei[1]]], dim=1)
-                    y = layer(h, ei, edge_attr, node_attr)
-                    gout = torch.randn(y.shape, generator=g2, dtype=torch.float32).to(dtype)
-                    (y * gout).sum().backward()
-                    out[f"{tag}/h"] = npy(h)
-                    out[f"{tag}/edge_index"] = npy(ei)
-                    out[f"{tag}/edge_attr"] = npy(edge_attr)
-                    out[f"{tag}/node_attr"] = npy(node_attr)
-                    out[f"{tag}/y"] = npy(y)
-                    out[f"{tag}/gout"] = npy(gout)
-                    out[f"{tag}/gh"] = npy(h.grad)
-                    if attr_grad:
-                        out[f"{tag}/g_edge_attr"] = npy(edge_attr.grad)
-                        out[f"{tag}/g_node_attr"] = npy(node_attr.grad)
-                    for k, v in params_of(layer).items():
-                        out[f"{tag}/p/{k}"] = v
-                    for k, v in layer.named_parameters():
-                        out[f"{tag}/g/{k}"] = npy(v.grad)
-        # no-attribute variant (edge_attr=None, node_attr=None), mean
-        tag = f"{dt_name}/noattr"
-        g2 = torch.Generator().manual_seed(43)
-        torch.manual_seed(43)
-        layer = R.EGCL(alg, C, C + 1, C, aggr="mean")
-        randomize_(layer, g2)
-        h = h0.clone().requires_grad_(True)
-        y = layer(h, ei)
-        gout = torch.randn(y.shape, generator=g2, dtype=torch.float32).to(dtype)
-        (y * gout).sum().backward()
-        out[f"{tag}/h"] = npy(h)
-        out[f"{tag}/edge_index"] = npy(ei)
-        out[f"{tag}/y"] = npy(y)
-        out[f"{tag}/gout"] = npy(gout)
-        out[f"{tag}/gh"] = npy(h.grad)
-        for k, v in params_of(layer).items():
-            out[f"{tag}/p/{k}"] = v
-        for k, v in layer.named_parameters():
-            out[f"{tag}/g/{k}"] = npy(v.grad)
+    N, E, C, T = 12, 40, 4, 3
+    # inputs are drawn once in float32 and cast; layers are initialised once in float32 and the
+    # float64 run loads the same parameters (round 1 drew them twice under different default
+    # dtypes: the f32 and f64 fixtures then described different layers)
     torch.set_default_dtype(torch.float32)
+    gen = torch.Generator().manual_seed(37)
+    ei = torch.randint(0, N - 1, (2, E), generator=gen)  # node N-1 is isolated
+    ei[:, 5] = ei[:, 4]            # duplicate edge
+    ei[:, 9] = ei[:, 4]            # triplicate
+    ei[1, 12] = ei[0, 12]          # self loop
+    ei[1, 20:28] = 3               # high in-degree node
+    types = torch.randint(0, T, (N,), generator=gen)
+    D = 1 << len(metric)
+    h0_32 = torch.randn(N, C, D, generator=gen, dtype=torch.float32)
+
+    def run(dt_name, dtype, layer, tag, h0, edge_attr, node_attr, attr_grad):
+        h = h0.clone().requires_grad_(True)
+        if attr_grad:
+            edge_attr = edge_attr.clone().requires_grad_(True)
+            node_attr = node_attr.clone().requires_grad_(True)
+        y = layer(h, ei, edge_attr, node_attr) if edge_attr is not None else layer(h, ei)
+        gout = torch.randn(y.shape, generator=torch.Generator().manual_seed(47), dtype=torch.float32).to(dtype)
+        (y * gout).sum().backward()
+        t = f"{dt_name}/{tag}"
+        out[f"{t}/h"] = npy(h)
+        out[f"{t}/edge_index"] = npy(ei)
+        if edge_attr is not None:
+            out[f"{t}/edge_attr"] = npy(edge_attr)
+            out[f"{t}/node_attr"] = npy(node_attr)
+        out[f"{t}/y"] = npy(y)
+        out[f"{t}/gout"] = npy(gout)
+        out[f"{t}/gh"] = npy(h.grad)
+        if attr_grad:
+            out[f"{t}/g_edge_attr"] = npy(edge_attr.grad)
+            out[f"{t}/g_node_attr"] = npy(node_attr.grad)
+        for k, v in params_of(layer).items():
+            out[f"{t}/p/{k}"] = v
+        for k, v in layer.named_parameters():
+            out[f"{t}/g/{k}"] = npy(v.grad)
+
+    variants = []
+    for aggr in ("sum", "mean"):
+        for residual in (True, False):
+            for attr_grad in (False, True):
+                if attr_grad and not residual:
+                    continue
+                variants.append((f"{aggr}_res{int(residual)}_ag{int(attr_grad)}", aggr, residual, attr_grad))
+    variants.append(("noattr", "mean", True, False))
+
+    for tag, aggr, residual, attr_grad in variants:
+        noattr = tag == "noattr"
+        torch.set_default_dtype(torch.float32)
+        alg32 = CliffordAlgebra(metric)
+        g2 = torch.Generator().manual_seed(41)
+        torch.manual_seed(41)
+        if noattr:
+            layer32 = R.EGCL(alg32, C, C + 1, C, aggr="mean")
+        else:
+            layer32 = R.EGCL(alg32, C, C, C, edge_attr_features=2 * T, node_attr_features=T,
+                             residual=residual, aggr=aggr)
+        randomize_(layer32, g2)
+        na0 = alg32.embed_grade(torch.nn.functional.one_hot(types, T).float()[..., None], 0)
+        if noattr:
+            ea32 = na32 = None
+        elif attr_grad:
+            na32 = na0 + 0.1 * torch.randn(na0.shape, generator=g2, dtype=torch.float32)
+            ea32 = torch.randn(E, 2 * T, D, generator=g2, dtype=torch.float32)
+        else:
+            na32 = na0.clone()
+            ea32 = torch.cat([na32[ei[0]], na32[ei[1]]], dim=1)
+        run("f32", torch.float32, layer32, tag, h0_32, ea32, na32, attr_grad)
+        torch.set_default_dtype(torch.float64)
+        alg64 = CliffordAlgebra(metric)
+        if noattr:
+            layer64 = R.EGCL(alg64, C, C + 1, C, aggr="mean")
+        else:
+            layer64 = R.EGCL(alg64, C, C, C, edge_attr_features=2 * T, node_attr_features=T,
+                             residual=residual, aggr=aggr)
+        _load_f32_params(layer64, layer32)
+        run("f64", torch.float64, layer64, tag, h0_32.double(),
+            None if ea32 is None else ea32.double(), None if na32 is None else na32.double(), attr_grad)
+        torch.set_default_dtype(torch.float32)
     np.savez_compressed(os.path.join(HERE, f"egcl_{name}.npz"), **out)
 
 

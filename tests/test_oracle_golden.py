@@ -123,3 +123,35 @@ def test_egcl_fwd_bwd(golden_dir, name, variant, prec):
     for k, v in p.items():
         ref = g[f"{tag}/g/{k}"]
         np.testing.assert_allclose(v.grad.numpy(), ref, rtol=rt * 10, atol=at * 10 * scale(ref))
+
+
+@pytest.mark.parametrize("name", ALGS)
+def test_egcl_fixture_runs_share_parameters(golden_dir, name):
+    """The f32 and f64 EGCL fixture runs must describe the same layer (round-1 fixtures did not)."""
+    g = load(golden_dir, "egcl", name)
+    n = 0
+    for k in g.files:
+        if k.startswith("f32/") and "/p/" in k:
+            assert np.abs(g[k].astype(np.float64) - g["f64/" + k[4:]]).max() <= 1e-6, k
+            n += 1
+    assert n > 0
+    for variant in EGCL_TAGS:
+        y32, y64 = g[f"f32/{variant}/y"], g[f"f64/{variant}/y"]
+        assert np.abs(y32 - y64).max() / np.abs(y64).max() < 1e-5
+
+
+@pytest.mark.parametrize("name", ALGS)
+def test_embed_grade_fixture(pkg, golden_dir, name):
+    """a6: embed_grade / get_grade of the product algebra against the reference fixture
+    (cliffordalgebra.py:105-117)."""
+    g = load(golden_dir, "algebra", name)
+    t = load(golden_dir, "tables", name)
+    alg = pkg.CliffordAlgebra(tuple(t["metric"].tolist()))
+    ref = torch.from_numpy(g["embed_grade1"])
+    n = len(t["metric"])
+    v = ref[..., 1:1 + n]
+    out = alg.embed_grade(v, 1)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    assert torch.equal(alg.get_grade(out, 1), v)
+    assert torch.equal(alg.embed(v, tuple(range(1, 1 + n))), ref)
+    assert torch.equal(alg.get(out, tuple(range(1, 1 + n))), v)
