@@ -13,6 +13,7 @@
 #include "../../include/csmpn_hip.h"
 #include "cemlp_kernel.hpp"
 #include "launch.hpp"
+#include "rl_launch.hpp"
 
 using namespace csmpn;
 
@@ -168,6 +169,8 @@ struct Plan {
     int var;              // VAR_WAVE / VAR_GROUP / VAR_GROUP_NM / VAR_GLOBAL
     int H;                // row halves per tile
     bool ps;              // parity-split kernels (cemlp_ps.hpp): 16-row tiles, 8 channels x 2 blade parities
+    void* workspace;      // the caller's workspace (the row-per-lane backward keeps its partial sums at its end)
+    size_t workspace_bytes;
 };
 
 // floats of one row tile's buffers; tiles are [channel][D][R] with channel stride R*D + 4
@@ -354,6 +357,8 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     if (nblk < 1 || nblk > CSMPN_MAX_BLOCKS) return fail(CSMPN_ERR_INVALID, "n_blocks=%d not in 1..%d", nblk, CSMPN_MAX_BLOCKS);
     const int D = 1 << n, G = n + 1, P = n_paths(id);
     memset(&plan, 0, sizeof(plan));
+    plan.workspace = workspace;
+    plan.workspace_bytes = workspace_bytes;
     DevCemlp& C = plan.C;
     C.nblk = nblk;
     int maxO = 0;
@@ -482,10 +487,68 @@ int run_pack(const Plan& plan, hipStream_t st) {
 
 unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of cycle accumulators
 
+// bytes of the row-per-lane backward's partial buffer (one slice of parameter-gradient sums per
+// workgroup), reserved at the END of the workspace; 0 when the shape is not served by those kernels
+size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n != 3 || nblk < 1 || nblk > 2) return 0;
+    const int ch = blocks[0].out_features;
+    for (int k = 0; k < nblk; ++k)
+        if (blocks[k].out_features != ch || (k > 0 && blocks[k].in_features != ch)) return 0;
+    return cemlp_rl_partial_floats_n3(nblk, ch, blocks[0].in_features) * sizeof(float) * kRlPartialGroups;
+}
+
+// Row-per-lane kernels (cemlp_rl.hpp): every block 8 channels wide, MVLinear with per-grade
+// weights, and (backward of a two-block CEMLP) the block-1 input saved by the forward.
+// CSMPN_NO_RL=1 keeps the generic kernels (A/B measurements, parity tests of both paths).
+bool rl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
+    static const bool off = getenv("CSMPN_NO_RL") && atoi(getenv("CSMPN_NO_RL"));
+    if (off || id != ALG_N3) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk < 1 || C.nblk > 2) return false;
+    const int ch = C.b[0].O;
+    for (int k = 0; k < C.nblk; ++k) {
+        if (C.b[k].O != ch || !C.b[k].w1_sub) return false;
+        if (k > 0 && C.b[k].I != ch) return false;
+    }
+    if (mode == MODE_EDGE && io.seg[0].ch != ch) return false;
+    if (mode == MODE_NODE && (io.seg[0].ch != ch || io.seg[1].ch != ch)) return false;
+    if (bwd && C.nblk > 1 && !io.saved) return false;
+    *channels = ch;
+    *i0 = C.b[0].I;
+    if (!has_cemlp_rl_n3(mode, C.nblk, ch, C.b[0].I)) return false;
+    if (bwd) {
+        const size_t pb = cemlp_rl_partial_floats_n3(C.nblk, ch, C.b[0].I) * sizeof(float) * kRlPartialGroups;
+        if (!plan.workspace || plan.workspace_bytes < pb) return false;
+    }
+    return true;
+}
+
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    {
+        int channels = 0, i0 = 0;
+        if (rl_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
+            const long rows_per_wave = 64 / (channels / 4);
+            const long tiles = (io.rows + rows_per_wave - 1) / rows_per_wave;
+            // one 4-wave workgroup per CU in the backward (512 VGPRs), two in the forward; few tiles
+            // spread one per workgroup (wave 0) over the CUs first
+            // tile t belongs to wave t % 4 of workgroup (t / 4) % grid
+            const long cap = bwd ? kRlMaxBwdGroups : 512;
+            const long groups = (tiles + 3) / 4;
+            const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            if (bwd) {
+                const size_t pb = cemlp_rl_partial_floats_n3(plan.C.nblk, channels, i0) * sizeof(float) * kRlPartialGroups;
+                io.rl_partials = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb) & ~(size_t)15));
+            }
+            bool handled = false;
+            static const bool debug_rl = getenv("CSMPN_DEBUG") != nullptr;
+            if (debug_rl) fprintf(stderr, "[csmpn] rl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
+            HIP_TRY(launch_cemlp_rl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
+            if (handled) return CSMPN_OK;
+        }
+    }
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
     // few tiles (e.g. the node update of a 10k-node complex): fewer row tiles per workgroup,
@@ -765,7 +828,7 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
         const size_t s2 = (size_t)kGlobalTileGrid * grt * Lf.total * 4;
         scratch = s2 > scratch ? s2 : scratch;
     }
-    return bytes + scratch;
+    return ((bytes + scratch + 15) & ~(size_t)15) + rl_partial_bytes(n, blocks, n_blocks) + 16;
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,

@@ -115,6 +115,7 @@ struct RowIO {
     float* save;
     const float* saved;
     unsigned long long* stamps;   // diagnostic (-DCSMPN_STAMPS) cycle accumulators, else null
+    float* rl_partials;     // row-per-lane backward (cemlp_rl.hpp): one slice of parameter-gradient sums per workgroup
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

@@ -319,11 +319,13 @@ def test_egcl_vs_oracle_shapes(pkg, metric, C, hidden, aggr):
 
 @pytest.mark.parametrize("N,E,seed", [(120, 1001, 2), (60, 400, 3)])
 def test_egcl_cl41_well_conditioned(pkg, N, E, seed):
-    """Cl(4,1), D = 32 kernels, forward and EVERY gradient at max(1e-5, 4 x yardstick) with a yardstick
-    <= 3e-6 (asserted): on random inputs the indefinite metric is ill-conditioned (null-cone norms)
-    and only a 1e-1 bound holds; here the e5-containing blades of h are scaled by 0.02."""
+    """Cl(4,1), D = 32 kernels, forward and EVERY gradient at max(1e-5, 4 x yardstick), where the
+    yardstick (error of the reference formulation's own float32 CPU run, host-dependent: 3e-6 in the
+    build container, 7e-6 on the GPU box) is asserted <= 1e-5 - the same level as the Euclidean
+    Cl(5,0) cases. On random inputs the indefinite metric is ill-conditioned (null-cone norms) and
+    only a 1e-1 bound holds; here the e5-containing blades of h are scaled by 0.02."""
     _oracle_egcl_case([1.0, 1.0, 1.0, 1.0, -1.0], N, E, 8, 8, "mean", seed=seed, neg_scale=0.02, slack=4.0,
-                      max_yard=3.5e-6)
+                      max_yard=1e-5)
 
 
 def test_egcl_edge_cases(pkg):
