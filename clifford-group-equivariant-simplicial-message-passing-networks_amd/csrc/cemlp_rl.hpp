@@ -592,34 +592,41 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
     ge.stamp(9);
     CSMPN_PHASE();
     // ---- geometric product backward (gz, gr accumulate; d/dw per path reduced at once)
-    f4 gr[D];
+    f4 gr[D], zf[D], rf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gr[d] = splat(0.f);
+    static_for<0, D>([&](auto d) {
+        zf[d] = S.gate[ALG::grade(d)] * S.y[d];
+        rf[d] = S.R[d] * S.invden[ALG::grade(d)];
+    });
     static_for<0, P>([&](auto p) {
         constexpr int gi = ALG::t.path_g[p][0], gj = ALG::t.path_g[p][1], gk = ALG::t.path_g[p][2];
         constexpr int i0 = ALG::gstart(gi), ni = ALG::gsize(gi);
         constexpr int j0 = ALG::gstart(gj), nj = ALG::gsize(gj);
         constexpr int k0 = ALG::gstart(gk), nk = ALG::gsize(gk);
         const f4 w = ld4(sp + (ST + LY::sw + C * p));
-        f4 U[ni], zi[ni], rk[nk];
+        // U[i] = sum sign ggp[j] r[k] (unweighted d/dz), V[k] = sum sign ggp[j] z[i] (unweighted d/dr)
+        f4 U[ni], V[nk];
 #pragma unroll
-        for (int t = 0; t < ni; ++t) { U[t] = splat(0.f); zi[t] = S.gate[gi] * S.y[i0 + t]; }
+        for (int t = 0; t < ni; ++t) U[t] = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < nk; ++t) rk[t] = S.R[k0 + t] * S.invden[gk];
+        for (int t = 0; t < nk; ++t) V[t] = splat(0.f);
         static_for<0, ni>([&](auto ii) {
             static_for<0, nk>([&](auto kk) {
                 constexpr int i = i0 + ii, k = k0 + kk;
                 constexpr int j = ALG::t.out[i][k];
                 if constexpr (j >= j0 && j < j0 + nj) {
                     constexpr float sg = float(ALG::t.sign[i][k]);
-                    U[ii] += (sg * ggp[j]) * rk[kk];
-                    gr[k] += (sg * w) * (ggp[j] * zi[ii]);
+                    U[ii] += (sg * ggp[j]) * rf[k];
+                    V[kk] += (sg * ggp[j]) * zf[i];
                 }
             });
         });
         f4 gwv = splat(0.f);
 #pragma unroll
-        for (int t = 0; t < ni; ++t) { gz[i0 + t] += w * U[t]; gwv += zi[t] * U[t]; }
+        for (int t = 0; t < ni; ++t) { gz[i0 + t] += w * U[t]; gwv += zf[i0 + t] * U[t]; }
+#pragma unroll
+        for (int t = 0; t < nk; ++t) gr[k0 + t] += w * V[t];
         red.template push<RM::i_w + p>(gwv);
     });
     ge.stamp(10);
@@ -902,6 +909,39 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
     ge.stamp_init();
     float* sc = lds + (BWD ? LY::sc_bwd + wave * LY::scratch : LY::sc_fwd + wave * LY::stage_floats);
 
+    constexpr int PIECE_ = 4 * ALG::D, ROW_ = C * ALG::D;
+    // the first tile's indices and first loads travel while the parameters are staged
+    const long ntiles = (io.rows + R - 1) / R;
+    const long tstride = (long)gridDim.x * kRlWaves;
+    struct TileRows { long row, lrow; bool valid; int i_dst, i_src, i_perm; float scale; };
+    auto tile_rows = [&](long t) {
+        TileRows T;
+        T.row = t * R + ge.r;
+        T.valid = t < ntiles && T.row < io.rows;
+        T.lrow = T.valid ? T.row : 0;   // invalid lanes compute on row 0 and contribute nothing
+        T.i_dst = T.i_src = T.i_perm = 0;
+        T.scale = 1.0f;
+        if constexpr (MODE == MODE_EDGE) {
+            T.i_dst = io.seg[0].ia[T.lrow];
+            T.i_src = io.seg[0].ib[T.lrow];
+            if constexpr (NA > 0) T.i_perm = io.seg[1].ia[T.lrow];
+        }
+        if constexpr (MODE == MODE_NODE) {   // mean aggregation
+            if (io.seg[1].deg) { const int dg = io.seg[1].deg[T.lrow]; T.scale = 1.0f / float(dg > 1 ? dg : 1); }
+        }
+        return T;
+    };
+    // backward: the tile's first loads
+    auto first_loads = [&](const TileRows& T, f4 (&gout)[ALG::D], f4 (&in1)[ALG::D]) {
+        const long srow = MODE == MODE_EDGE ? (long)T.i_dst : T.lrow;
+        rl_load_t<ALG>(gout, io.gy + (size_t)srow * ROW_ + ge.og * PIECE_);
+        if constexpr (NBLK > 1) rl_load_t<ALG>(in1, io.saved + (size_t)T.lrow * ROW_ + ge.og * PIECE_);
+    };
+    long tile = (long)blockIdx.x * kRlWaves + wave;
+    TileRows Tn = tile_rows(tile);
+    f4 gout_n[ALG::D], in1_n[ALG::D];
+    if constexpr (BWD) first_loads(Tn, gout_n, in1_n);
+
     rl_stage_store<LY, I0>(Cd.b[0], lds + ST0, threadIdx.x);
     if constexpr (NBLK > 1) rl_stage_store<LY, C>(Cd.b[1], lds + ST1, threadIdx.x);
     __syncthreads();
@@ -923,40 +963,10 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
         for (int c = 0; c < NBLK * LY::n_chunk; ++c) *reinterpret_cast<f4*>(tot_0 + ge.r_t + c * 256) = splat(0.f);
     }
 
-    const long ntiles = (io.rows + R - 1) / R;
-    const long tstride = (long)gridDim.x * kRlWaves;
     // Software pipeline over the wave's tiles (one wave per SIMD in the backward: nothing else hides a
     // memory round trip). The row indices of tile t+1 are loaded while tile t computes; in the
     // backward the first loads of tile t+1 (incoming gradient, saved block input) are issued BEFORE
     // the scatter atomics of tile t, so that waiting for them does not wait for the atomics.
-    struct TileRows { long row, lrow; bool valid; int i_dst, i_src, i_perm; float scale; };
-    auto tile_rows = [&](long t) {
-        TileRows T;
-        T.row = t * R + ge.r;
-        T.valid = t < ntiles && T.row < io.rows;
-        T.lrow = T.valid ? T.row : 0;   // invalid lanes compute on row 0 and contribute nothing
-        T.i_dst = T.i_src = T.i_perm = 0;
-        T.scale = 1.0f;
-        if constexpr (MODE == MODE_EDGE) {
-            T.i_dst = io.seg[0].ia[T.lrow];
-            T.i_src = io.seg[0].ib[T.lrow];
-            if constexpr (NA > 0) T.i_perm = io.seg[1].ia[T.lrow];
-        }
-        if constexpr (MODE == MODE_NODE) {   // mean aggregation
-            if (io.seg[1].deg) { const int dg = io.seg[1].deg[T.lrow]; T.scale = 1.0f / float(dg > 1 ? dg : 1); }
-        }
-        return T;
-    };
-    // backward: the tile's first loads
-    auto first_loads = [&](const TileRows& T, f4 (&gout)[D], f4 (&in1)[D]) {
-        const long srow = MODE == MODE_EDGE ? (long)T.i_dst : T.lrow;
-        rl_load_t<ALG>(gout, io.gy + (size_t)srow * ROW + ge.og * PIECE);
-        if constexpr (NBLK > 1) rl_load_t<ALG>(in1, io.saved + (size_t)T.lrow * ROW + ge.og * PIECE);
-    };
-    long tile = (long)blockIdx.x * kRlWaves + wave;
-    TileRows Tn = tile_rows(tile);
-    f4 gout_n[D], in1_n[D];
-    if constexpr (BWD) first_loads(Tn, gout_n, in1_n);
     for (; tile < ntiles; tile += tstride) {
         const TileRows Tc = Tn;
         const long row = Tc.row, lrow = Tc.lrow;
