@@ -1,0 +1,173 @@
+"""Callers either side of the shared simplicial message-passing path (SURVEY.md §8(f)-1,2):
+the simplex feature embedding in front of the EGCL stack and the readout + loss behind it, as
+the reference's task models compose them, on the HIP-backed layers of this package.
+
+    SimplexEmbedding   embed_simplicial_complex (hulls_cssmpnn.py:96-125, md17_cssmpnn.py:85-120):
+                       vertex features of every d-simplex in all (d+1)! vertex orders -> grade
+                       embedding -> MVLinear (d = 0) / CEMLP(n_layers = d) -> sum over the orders
+    type_attributes    embed_simplex_types (hulls_cssmpnn.py:127-140, md17_cssmpnn.py:122-133)
+    HullsSimplicialMPNN  convex-hull volume model: 3 x EGCL -> MVLinear -> scalar blade ->
+                       mean over the simplices of a graph -> MSE (hulls_cssmpnn.py:89-164)
+    MD17SimplicialMPNN   trajectory model: MVLinear featurisation, 5 x EGCL (aggr = sum, learned
+                       type attributes), CEMLP + MVLinear head on the vertices, vector blades ->
+                       MSE / ADE / FDE (md17_cssmpnn.py:135-176)
+
+Attribute names follow the reference so that its checkpoints load (`state_dict` keys are the
+contract); the bodies are this package's own. Batches are
+csmpn.data.complexes.SimplicialBatch (no torch_geometric).
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import List, Sequence, Tuple
+
+import torch
+from torch import nn
+
+from csmpn.algebra.cliffordalgebra import CliffordAlgebra
+from csmpn.models.cegnn_utils import CEMLP, EGCL, MVLinear
+
+
+def segment_mean(x: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
+    """global_mean_pool: mean of the rows of x per segment id (sum / clamp(count, 1))."""
+    out = x.new_zeros((n,) + tuple(x.shape[1:]))
+    out.index_add_(0, index, x)
+    cnt = x.new_zeros(n)
+    cnt.index_add_(0, index, torch.ones_like(index, dtype=x.dtype))
+    return out / cnt.clamp(min=1).reshape((-1,) + (1,) * (x.dim() - 1))
+
+
+def simplex_vertex_rows(batch) -> torch.Tensor:
+    """Row (in the batch) of every vertex of every simplex: x_ind is local to its graph."""
+    start = batch.x_ind_ptr[:-1][batch.x_ind_batch]
+    return batch.x_ind.long() + start.unsqueeze(-1)
+
+
+class SimplexEmbedding(nn.Module):
+    """cl_feature_embedding of the task models: module d embeds the d-simplices."""
+
+    def __init__(self, algebra: CliffordAlgebra, in_features: int, hidden_features: int, max_dim: int = 2):
+        super().__init__()
+        self.algebra = algebra
+        self.hidden_features = hidden_features
+        self.max_dim = max_dim
+        self.cl_feature_embedding = nn.ModuleList(
+            [MVLinear(algebra, in_features, hidden_features, subspaces=False)]
+            + [CEMLP(algebra, (d + 1) * in_features, hidden_features, hidden_features, n_layers=d, normalization_init=0)
+               for d in range(1, max_dim + 1)])
+
+    def forward(self, batch, vertex_blocks: Sequence[Tuple[torch.Tensor, int]]) -> torch.Tensor:
+        """vertex_blocks: [(tensor [S, K, n_g], grade g)]: K channels per vertex, embedded as grade g.
+        Channel order of a d-simplex row: block by block, inside a block vertex by vertex."""
+        rows = simplex_vertex_rows(batch)
+        D = 2 ** self.algebra.dim
+        out = torch.zeros(batch.x_ind.shape[0], self.hidden_features, D, device=batch.x_ind.device)
+        for d in range(self.max_dim + 1):
+            sel = batch.node_types == d
+            verts = rows[sel, : d + 1]                      # [n_d, d+1]
+            if verts.shape[0] == 0:
+                continue
+            perms = torch.tensor(list(itertools.permutations(range(d + 1))), device=verts.device)
+            nperm = math.factorial(d + 1)
+            pv = verts[:, perms].reshape(-1, d + 1)         # [n_d * (d+1)!, d+1]
+            feats = []
+            for t, grade in vertex_blocks:
+                g = t[pv]                                   # [rows, d+1, K, n_g]
+                g = g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2])
+                feats.append(self.algebra.embed_grade(g, grade))
+            x = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)
+            e = self.cl_feature_embedding[d](x.contiguous())
+            out[sel] = e.reshape(verts.shape[0], nperm, self.hidden_features, D).sum(dim=1)
+        return out
+
+
+def type_attributes(algebra: CliffordAlgebra, type_features: torch.Tensor, edge_index: torch.Tensor):
+    """node_attr = per-simplex type features as scalar-blade multivectors, edge_attr = (source, target)."""
+    node_attr = algebra.embed_grade(type_features.unsqueeze(-1), 0)
+    edge_attr = torch.cat((node_attr[edge_index[0]], node_attr[edge_index[1]]), dim=1)
+    return node_attr, edge_attr
+
+
+class HullsSimplicialMPNN(nn.Module):
+    def __init__(self, in_features=1, hidden_features=28, out_features=1, num_layers=3, normalization_init=0,
+                 residual=True, aggr="mean", condition=True, max_dim: int = 2):
+        super().__init__()
+        self.max_dim = max_dim
+        self.algebra = CliffordAlgebra((1.0, 1.0, 1.0, 1.0, 1.0))
+        self.hidden_features = hidden_features
+        self.num_node_type = max_dim + 1 if condition else 0
+        emb = SimplexEmbedding(self.algebra, in_features, hidden_features, max_dim)
+        self.cl_feature_embedding = emb.cl_feature_embedding   # reference attribute name
+        object.__setattr__(self, "_embed", emb)                # not a second registration
+        self.layers = nn.Sequential(*[
+            EGCL(self.algebra, hidden_features, hidden_features, hidden_features,
+                 edge_attr_features=2 * self.num_node_type, node_attr_features=self.num_node_type,
+                 residual=residual, normalization_init=normalization_init, aggr=aggr)
+            for _ in range(num_layers)])
+        self.projection = nn.Sequential(MVLinear(self.algebra, hidden_features, out_features))
+        self.readout = nn.Linear(3, 1)   # present (unused) in the reference: kept for strict checkpoint loading
+
+    def forward(self, batch, step=0, mode="train"):
+        B = batch.num_graphs
+        n = self.algebra.dim
+        inp = batch.input
+        # centre the vertices of every graph (hulls_cssmpnn.py:145-148)
+        is_v = batch.node_types == 0
+        pos = inp[is_v].reshape(B, -1, n)
+        centred = (pos - pos.mean(dim=1, keepdim=True)).reshape(-1, n)
+        inp = inp.clone()
+        inp[is_v] = centred
+        x = self._embed(batch, [(inp.unsqueeze(1), 1)])
+        types = torch.nn.functional.one_hot(batch.node_types, self.num_node_type).float()
+        node_attr, edge_attr = type_attributes(self.algebra, types, batch.edge_index)
+        for layer in self.layers:
+            x = layer(x, batch.edge_index, node_attr=node_attr, edge_attr=edge_attr)
+        pred = self.projection(x)[:, :, 0]
+        pred = segment_mean(pred, batch.x_ind_batch, B)
+        loss = (pred.squeeze(-1) - batch.target) ** 2
+        return loss.mean(0), {"loss": loss}
+
+
+class MD17SimplicialMPNN(nn.Module):
+    def __init__(self, max_dim: int = 2, num_input: int = 30, num_hidden: int = 32, num_out: int = 10,
+                 num_layers: int = 5, condition=True):
+        super().__init__()
+        self.algebra = CliffordAlgebra((1.0, 1.0, 1.0))
+        self.max_dim = max_dim
+        self.num_hidden = num_hidden
+        self.num_node_type = max_dim + 1 if condition else 0
+        self.feature_embedding = MVLinear(self.algebra, num_hidden + self.num_node_type, num_hidden, subspaces=False)
+        emb = SimplexEmbedding(self.algebra, num_input, num_hidden, max_dim)
+        self.cl_feature_embedding = emb.cl_feature_embedding
+        object.__setattr__(self, "_embed", emb)
+        self.sim_type_embedding = nn.Embedding(num_embeddings=max_dim + 1, embedding_dim=max_dim + 1)
+        self.layers = nn.ModuleList([
+            EGCL(self.algebra, num_hidden, num_hidden, num_hidden, edge_attr_features=2 * self.num_node_type,
+                 node_attr_features=self.num_node_type, aggr="sum", normalization_init=0)
+            for _ in range(num_layers)])
+        self.projection = nn.Sequential(CEMLP(self.algebra, num_hidden, num_hidden, num_hidden, n_layers=1),
+                                        MVLinear(self.algebra, num_hidden, num_out))
+
+    def forward(self, batch, step=0, mode="train"):
+        B = batch.num_graphs
+        F_ = batch.loc.shape[1]                       # frames
+        is_v = batch.node_types == 0
+        loc_node = batch.loc[is_v]
+        # mean position of a graph's vertices over vertices and frames (md17_cssmpnn.py:135-139)
+        per_graph = segment_mean(loc_node.reshape(-1, F_ * 3), batch.batch[is_v], B).reshape(B, F_, 3)
+        per_graph = per_graph.mean(dim=1, keepdim=True).expand(B, F_, 3)
+        pos = batch.loc - per_graph[batch.x_ind_batch]
+        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        x = self._embed(batch, [(pos, 1), (batch.vel, 1), (batch.charges, 0)])
+        x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
+        for layer in self.layers:
+            x = layer(x, batch.edge_index, edge_attr, node_attr)
+        pred = self.projection(x[is_v].contiguous())[..., 1:4]
+        loc_pred = loc_node + pred
+        tgt = batch.y
+        sq = ((loc_pred.reshape(-1, 3) - tgt.reshape(-1, 3)) ** 2)
+        ade = sq.sum(-1).sqrt().reshape(B, -1, F_).mean(-1).mean(-1)
+        fde = ((loc_pred[:, -1, :] - tgt[:, -1, :]) ** 2).sum(-1).sqrt().reshape(B, -1).mean(-1)
+        loss = sq.reshape(B, -1, 3).sum(-1).mean(-1)
+        return loss.mean(), {"loss": loss, "ade_loss": ade, "fde_loss": fde}

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("CSMPN_LIB") or os.path.join(_HERE, "libcsmpn_hip.so")
 
 MAX_BLOCKS = 4
 FLAG_WEIGHTS_PACKED = 1
+FLAG_NO_VALIDATE = 2
 
 # every symbol include/csmpn_hip.h declares
 EXPORTS = (
@@ -26,6 +27,7 @@ EXPORTS = (
     "csmpn_cemlp_backward",
     "csmpn_mvlinear_forward",
     "csmpn_mvlinear_backward",
+    "csmpn_csr_workspace_bytes",
     "csmpn_csr_build",
     "csmpn_egcl_edge_forward",
     "csmpn_egcl_edge_backward",
@@ -83,7 +85,8 @@ def _load():
     sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_mvlinear_forward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp])
     sig("csmpn_mvlinear_backward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp])
-    sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp])
+    sig("csmpn_csr_workspace_bytes", sz, [i64, i64])
+    sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_edge_forward", C.c_int,
         [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_edge_backward", C.c_int,

@@ -186,7 +186,7 @@ def cemlp_apply(x, binding: CemlpBinding, params):
 class Csr:
     """Target-sorted adjacency of one complex (built once, reused by every layer and step)."""
 
-    __slots__ = ("perm", "src", "dst", "deg", "row_ptr", "n_edges", "n_nodes", "_scratch")
+    __slots__ = ("perm", "src", "dst", "deg", "row_ptr", "n_edges", "n_nodes", "build_ms")
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int):
         if not edge_index.is_cuda:
@@ -203,10 +203,17 @@ class Csr:
         self.dst = torch.empty(max(E, 1), **i32)
         self.deg = torch.empty(n_nodes, **i32)
         self.row_ptr = torch.empty(n_nodes + 1, **i32)
-        self._scratch = torch.empty(n_nodes + 1, **i32)
-        check(native.lib().csmpn_csr_build(ei.data_ptr(), E, n_nodes, self.perm.data_ptr(), self.src.data_ptr(),
-                                           self.dst.data_ptr(), self.deg.data_ptr(), self.row_ptr.data_ptr(),
-                                           self._scratch.data_ptr(), _stream(dev)))
+        ws = torch.empty(int(native.lib().csmpn_csr_workspace_bytes(E, n_nodes)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+            # validates edge_index against [0, n_nodes) (raises CsmpnError); one host sync per complex
+            check(native.lib().csmpn_csr_build(ei.data_ptr(), E, n_nodes, self.perm.data_ptr(), self.src.data_ptr(),
+                                               self.dst.data_ptr(), self.deg.data_ptr(), self.row_ptr.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), 0, _stream(dev)))
+            t1.record()
+            t1.synchronize()
+            self.build_ms = t0.elapsed_time(t1)
 
 
 class CsrSlice:

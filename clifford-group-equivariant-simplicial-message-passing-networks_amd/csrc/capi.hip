@@ -11,23 +11,26 @@
 #include <vector>
 
 #include "../../include/csmpn_hip.h"
+#include "capi_common.hpp"
 #include "cemlp_kernel.hpp"
 #include "launch.hpp"
 #include "rl_launch.hpp"
 
 using namespace csmpn;
 
-namespace {
+thread_local char g_csmpn_err[512] = "";
 
-thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
+int csmpn_fail(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    vsnprintf(g_csmpn_err, sizeof(g_csmpn_err), fmt, ap);
     va_end(ap);
     return code;
 }
+
+namespace {
+
+#define fail csmpn_fail
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -664,66 +667,12 @@ int mvlinear_desc(int n, long rows, int I, int O, int sub, MvLinDesc& P) {
     return CSMPN_OK;
 }
 
-// ----------------------------------------------------------------------------- CSR build kernels
-__global__ void csr_count_kernel(const int64_t* dst, long E, int* deg) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E) atomicAdd(deg + dst[e], 1);
-}
-
-// exclusive scan of deg[0..N) into row_ptr[0..N], single workgroup of 1024 threads
-__global__ void csr_scan_kernel(const int* deg, int* row_ptr, int* cursor, long N) {
-    __shared__ int part[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (long base = 0; base < N; base += 1024) {
-        const long i = base + threadIdx.x;
-        const int v = i < N ? deg[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int s = 1; s < 1024; s <<= 1) {
-            int t = threadIdx.x >= s ? part[threadIdx.x - s] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const int incl = part[threadIdx.x];
-        if (i < N) { row_ptr[i] = carry + incl - v; cursor[i] = carry + incl - v; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) row_ptr[N] = carry;
-}
-
-__global__ void csr_fill_kernel(const int64_t* ei, long E, int* cursor, int* perm, int* src_s, int* dst_s) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
-    const int d = (int)ei[E + e], s = (int)ei[e];
-    const int pos = atomicAdd(cursor + d, 1);
-    perm[pos] = (int)e; src_s[pos] = s; dst_s[pos] = d;
-}
-
-// make the order inside each target segment canonical (ascending original edge id):
-// one thread per node, insertion sort of its (short) segment
-__global__ void csr_canon_kernel(const int* row_ptr, long N, int* perm, int* src_s) {
-    const long v = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= N) return;
-    const int b = row_ptr[v], e = row_ptr[v + 1];
-    for (int i = b + 1; i < e; ++i) {
-        const int kp = perm[i], ks = src_s[i];
-        int j = i - 1;
-        while (j >= b && perm[j] > kp) { perm[j + 1] = perm[j]; src_s[j + 1] = src_s[j]; --j; }
-        perm[j + 1] = kp; src_s[j + 1] = ks;
-    }
-}
-
 }  // namespace
 
 // =============================================================================== C-ABI
 extern "C" {
 
-const char* csmpn_last_error(void) { return g_err; }
+const char* csmpn_last_error(void) { return g_csmpn_err; }
 
 /* diagnostic (-DCSMPN_STAMPS builds): device buffer of 25 uint64 per-phase cycle sums + wave count */
 void csmpn_debug_set_stamps(void* device_u64x25) { g_stamps = static_cast<unsigned long long*>(device_u64x25); }
@@ -900,26 +849,6 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
     if (g_weight) {
         const unsigned grid = (unsigned)((rows + kMvLinSlab - 1) / kMvLinSlab);
         hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
-    }
-    HIP_TRY(hipGetLastError());
-    return CSMPN_OK;
-}
-
-int csmpn_csr_build(const int64_t* edge_index, int64_t E, int64_t N, int32_t* perm, int32_t* src_sorted,
-                    int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr, int32_t* scratch, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (N <= 0 || E < 0 || N >= (1ll << 31) || E >= (1ll << 31)) return fail(CSMPN_ERR_INVALID, "bad sizes N=%lld E=%lld", (long long)N, (long long)E);
-    HIP_TRY(hipMemsetAsync(in_degree, 0, sizeof(int) * (size_t)N, st));
-    if (E > 0) {
-        const unsigned block = 256, grid = (unsigned)((E + block - 1) / block);
-        hipLaunchKernelGGL(csr_count_kernel, dim3(grid), dim3(block), 0, st, edge_index + E, (long)E, in_degree);
-    }
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, in_degree, row_ptr, scratch, (long)N);
-    if (E > 0) {
-        const unsigned block = 256, grid = (unsigned)((E + block - 1) / block);
-        hipLaunchKernelGGL(csr_fill_kernel, dim3(grid), dim3(block), 0, st, edge_index, (long)E, scratch, perm, src_sorted, dst_sorted);
-        const unsigned gridn = (unsigned)((N + block - 1) / block);
-        hipLaunchKernelGGL(csr_canon_kernel, dim3(gridn), dim3(block), 0, st, row_ptr, (long)N, perm, src_sorted);
     }
     HIP_TRY(hipGetLastError());
     return CSMPN_OK;

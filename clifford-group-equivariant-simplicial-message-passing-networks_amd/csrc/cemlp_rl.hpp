@@ -243,7 +243,7 @@ __device__ void rl_stage_store(const DevBlock& B, float* st, int tid) {
     }
 }
 
-// second kernel of a backward: grads += sum over the waves' slices, fixed order (deterministic).
+// second kernel of a backward: grads += sum over the workgroups' slices, fixed order (deterministic).
 // A workgroup takes 16 consecutive elements; thread (j = tid & 15, w0 = tid >> 4) adds the slices
 // w0, w0 + 16, ... of element 16 b + j, the 16 partial sums meet in LDS and are added in order.
 template <class ALG, int NOG, int NBLK, int I0>
@@ -254,8 +254,16 @@ __global__ void __launch_bounds__(256) rl_reduce_kernel(const DevCemlp C_arg, co
     const int j = threadIdx.x & 15, w0 = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + j;
     float s = 0.f;
-    if (e < LY::part_total)
-        for (int w = w0; w < nslices; w += 16) s += part[(size_t)w * LY::part_total + e];
+    if (e < LY::part_total) {
+        const float* p = part + e;
+        int w = w0;
+        for (; w + 48 < nslices; w += 64) {   // four independent loads in flight
+            const float a = p[(size_t)w * LY::part_total], b = p[(size_t)(w + 16) * LY::part_total];
+            const float c = p[(size_t)(w + 32) * LY::part_total], d = p[(size_t)(w + 48) * LY::part_total];
+            s += (a + b) + (c + d);
+        }
+        for (; w < nslices; w += 16) s += p[(size_t)w * LY::part_total];
+    }
     red[w0][j] = s;
     __syncthreads();
     if (w0 != 0 || e >= LY::part_total) return;
@@ -1171,11 +1179,19 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
 
     if constexpr (BWD) {
         static_assert(LY::part_total <= LY::tot_off && LY::part_total % 4 == 0, "slice image must fit below the totals");
-        float* part = io.rl_partials + ((size_t)blockIdx.x * kRlWaves + wave) * LY::part_total;
+        // every wave builds the image of its sums in its own scratch; the workgroup adds the four
+        // images in wave order and writes ONE slice (coalesced 16-byte stores)
         rl_partials_image<ALG, NOG, 0>(sc + LY::part_off(0), ge, accW1_0, accRL_0, tot_0);
         if constexpr (NBLK > 1) rl_partials_image<ALG, NOG, 1>(sc + LY::part_off(1), ge, accW1_1, accRL_1, tot_1);
-        for (int e = 4 * ge.lane; e < LY::part_total; e += 256)
-            *reinterpret_cast<f4*>(part + e) = ld4(sc + e);
+        __syncthreads();
+        float* part = io.rl_partials + (size_t)blockIdx.x * LY::part_total;
+        const float* img = lds + LY::sc_bwd;
+        for (int e = 4 * threadIdx.x; e < LY::part_total; e += 4 * 64 * kRlWaves) {
+            f4 v = ld4(img + e);
+#pragma unroll
+            for (int w = 1; w < kRlWaves; ++w) v += ld4(img + w * LY::scratch + e);
+            *reinterpret_cast<f4*>(part + e) = v;
+        }
     }
 #ifdef CSMPN_STAMPS
     ge.stamp(19);

@@ -6,7 +6,7 @@
 
 namespace csmpn {
 constexpr int kRlMaxBwdGroups = 256;    // workgroups of a row-per-lane backward (one 4-wave group per CU)
-constexpr int kRlPartialGroups = 4 * kRlMaxBwdGroups;   // slices of its partial buffer: one per wave
+constexpr int kRlPartialGroups = kRlMaxBwdGroups;       // slices of its partial buffer: one per workgroup
 // row-per-lane kernels (cemlp_rl.hpp): narrow layers, every block 8 output channels
 #define CSMPN_DECLARE_RL(tag)                                                                                  \
     bool has_cemlp_rl_##tag(int mode, int nblk, int channels, int i0);                                          \

@@ -48,6 +48,7 @@ extern "C" {
 #define CSMPN_ERR_HIP 3
 
 /* flags of the compute entry points */
+#define CSMPN_FLAG_NO_VALIDATE 2u    /* csmpn_csr_build: skip the (synchronous) range check of edge_index */
 #define CSMPN_FLAG_WEIGHTS_PACKED 1u /* forward entry points: the workspace already holds this
                                        CEMLP's packed weights (left there by an earlier forward with
                                        the same parameters): skip the pack kernel. Accepted and
@@ -141,15 +142,20 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
                             int32_t in_features, int32_t out_features, int32_t subspaces, float* gx, float* g_weight,
                             float* g_bias, void* stream);
 
-/* One-time per complex: sort the E directed adjacencies by target.
+/* One-time per complex: sort the E directed adjacencies by target (stable radix sort).
  * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
  * Outputs (device): perm[E] (sorted position -> original edge id), src_sorted[E],
  * dst_sorted[E] (int32), in_degree[N] (int32), row_ptr[N+1] (int32).
- * scratch: N+1 int32. Inside one target's segment the edges keep ascending original
- * id, so the result (and the summation order downstream) is deterministic. */
+ * workspace: csmpn_csr_workspace_bytes(E, N) bytes of device memory. Inside one target's
+ * segment the edges keep ascending original id, so the result (and the summation order
+ * downstream) is deterministic. Every index is range-checked against [0, N): an entry outside
+ * returns CSMPN_ERR_INVALID (PyG's scatter asserts in that case); the check costs one host
+ * synchronisation per call - complexes are static and the result is cached by the caller -
+ * and is skipped with CSMPN_FLAG_NO_VALIDATE (out-of-range entries are then mapped to node 0). */
+size_t csmpn_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
 int csmpn_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
                     int32_t* src_sorted, int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr,
-                    int32_t* scratch, void* stream);
+                    void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* EGCL message + aggregate (cegnn_utils.py:254-262 + PyG scatter):
  *   agg[v] += sum_{e: dst_e = v} EdgeCEMLP(cat_c[h[dst_e] - h[src_e], edge_attr[perm_e]])

@@ -405,6 +405,34 @@ def test_csr_build(pkg):
     assert torch.all(seg[1:] > seg[:-1])
 
 
+def test_csr_build_hub_and_validation(pkg):
+    """A hub with 200k incoming edges sorts like any other input (round 1: per-node insertion sort,
+    O(deg^2)); indices outside [0, N) are rejected (PyG's scatter asserts there) instead of driving the
+    gathers / scatters out of bounds."""
+    from csmpn_hip import native, ops
+    N, E = 1000, 200_000
+    g = torch.Generator().manual_seed(4)
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.full((E,), 7)])
+    csr = ops.Csr(ei.to(dev()), N)
+    torch.cuda.synchronize()
+    assert csr.build_ms < 50.0
+    perm = csr.perm.cpu().long()
+    assert torch.equal(perm, torch.arange(E))                      # stable: one segment, original order
+    assert int(csr.deg[7]) == E and int(csr.row_ptr[7]) == 0 and int(csr.row_ptr[8]) == E
+    for bad in (N, -1):
+        ei2 = ei.clone()
+        ei2[1, 123] = bad
+        with pytest.raises(native.CsmpnError, match="outside"):
+            ops.Csr(ei2.to(dev()), N)
+        ei3 = ei.clone()
+        ei3[0, 5] = bad
+        with pytest.raises(native.CsmpnError, match="outside"):
+            ops.Csr(ei3.to(dev()), N)
+    # empty edge list
+    c0 = ops.Csr(torch.zeros(2, 0, dtype=torch.int64, device=dev()), 5)
+    assert c0.deg.sum().item() == 0 and c0.row_ptr.cpu().tolist() == [0] * 6
+
+
 def test_equivariance_rotation(pkg):
     """O(3)-equivariance of the HIP layer: rotating every multivector input by a rotor
     commutes with the layer (property the reference layers have)."""
