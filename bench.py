@@ -13,9 +13,13 @@ on synthetic input already resident in HBM.
 
 Workload (BASELINE.json configs[1]): S1 = Cl(3,0), 8 channels,
 10 000 nodes, 100 000 directed adjacencies per GPU, aggr=mean, seeded generator.
-With N > 1 GPUs the adjacency list of an N x 100k-edge complex over the same 10k
-nodes is sharded (100k edges per rank, weak scaling); each step all-reduces the
-per-node aggregate (forward) and [d/dh | edge-model gradients] (backward) over RCCL.
+With N > 1 GPUs the adjacency list of an N x 100k-edge complex over the same 10k nodes is
+sharded (100k edges per rank, weak scaling). Default partitioning B (csmpn_hip/sharded.py): every
+rank owns N/W nodes and all edges into them - all-gather of the updated node slices forward,
+reduce-scatter of d/dh backward, all-reduce of the parameter gradients; `--partition A` = contiguous
+edge shards with an all-reduce of the per-node aggregate (forward) and of [d/dh | edge-model
+gradients] (backward). `--scaling strong --workload S2` shards ONE 1M-edge complex (north_star's
+multi-GPU configuration) instead and also reports the compute-only rate and the bus bandwidth.
 """
 import argparse
 import importlib
@@ -52,24 +56,39 @@ def algorithmic_bytes(C, D, A=6, T=3):
     }
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this
-    same workload (separate --pmc passes, tools/profile_r01.sh): 2 x FETCH_SIZE (gfx950 counts a
-    wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> B.
-    None when no summary is committed (counters cannot be read from inside the timed run)."""
+def kernel_of(stage, name):
+    """Does the rocprofv3 kernel name belong to this stage? (MODE 1 = edge, 2 = node; last template
+    argument = backward.) cemlp_rl_kernel<Alg, NOG, MODE, NBLK, I0, BWD>, cemlp_kernel<Alg, MODE, ...>,
+    cemlp_ps_kernel<Alg, MODE, BWD>."""
+    import re
+    m = re.search(r"cemlp(_rl|_ps)?_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+    if not m:
+        return False
+    args = [a.strip() for a in m.group(2).split(",")]
+    mode = args[1] if m.group(1) == "_rl" else args[0]
+    return mode == ("1" if stage.startswith("edge") else "2") and args[-1] == ("true" if stage.endswith("bwd") else "false")
+
+
+def pmc_traffic(stage, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS
+    workload (separate --pmc passes, tools/profile_r02.sh -> profiles/r02_<workload>_pmc_summary.json):
+    2 x FETCH_SIZE (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM
+    section) + WRITE_SIZE, KB -> B. None when no summary of this workload is committed (counters cannot
+    be read from inside the timed run)."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    path = found[-1] if found else ""   # the latest committed summary
-    tag = {"edge_fwd": "1, 0, 2, false", "edge_bwd": "1, 0, 2, true", "node_fwd": "2, 0, 1, false",
-           "node_bwd": "2, 0, 1, true"}.get(stage)
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_summary.json")))
+    if not found:
+        return None
     try:
-        with open(path) as f:
+        with open(found[-1]) as f:
+            best = None
             for name, c in json.load(f).items():
-                if tag and f"Alg<3, 0u>, {tag}>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                if kernel_of(stage, name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    t = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+                    best = t if best is None or t > best else best
+            return best
     except OSError:
-        pass
-    return None
+        return None
 
 
 def make_inputs(metric, C, N, E_total, lo, hi, device):
@@ -113,13 +132,14 @@ def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0):
     probe_e = min(2000, ei.shape[1])
     run(probe_e)                      # warm-up (thread pool, allocator)
     t_probe = run(probe_e)
-    reps = 3
+    reps = 5
     ne = int(min(ei.shape[1], max(probe_e, probe_e * budget_s / (reps * max(t_probe, 1e-4)))))
     times = [run(ne) for _ in range(reps)]
     med = statistics.median(times)
-    return {"value": ne / med, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"first {ne} of {ei.shape[1]} edges over the same {h.shape[0]} nodes, fwd+bwd, median of "
-                      f"{reps} runs ({med:.3f} s each), torch {torch.__version__} CPU threads={cores}"}
+    return {"value": ne / med, "unit": "edges/s", "cores": cores, "kind": "port", "host_cores": os.cpu_count(),
+            "sample": f"{'all' if ne == ei.shape[1] else 'first'} {ne} of {ei.shape[1]} edges over the same "
+                      f"{h.shape[0]} nodes, fwd+bwd, median of {reps} runs ({med:.3f} s each), torch "
+                      f"{torch.__version__} CPU threads={cores} of {os.cpu_count()} host cores"}
 
 
 def main():
@@ -134,6 +154,10 @@ def main():
     ap.add_argument("--segments", action="store_true",
                     help="run the N>1 launch path (graph segments + eager collectives) on one GPU too")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = the workload's edges PER rank; strong = ONE complex sharded over the ranks")
+    ap.add_argument("--partition", default="B", choices=["A", "B"],
+                    help="N > 1: B = destination-partitioned (all-gather / reduce-scatter), A = edge shards (all-reduce)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,8 +183,12 @@ def main():
 
     metric, C, N, E_per = WORKLOADS[args.workload]
     D = 1 << len(metric)
-    E_total = E_per * world
-    lo, hi = sharded.shard_bounds(E_total, world, rank)
+    E_total = E_per * world if args.scaling == "weak" else E_per
+    part_b = world > 1 and args.partition == "B"
+    if part_b:
+        lo, hi = 0, E_total            # replicated topology; every rank selects the edges into its nodes
+    else:
+        lo, hi = sharded.shard_bounds(E_total, world, rank)
     (h, ei, ea, na), cpu_inputs = make_inputs(metric, C, N, E_total, lo, hi, device)
 
     torch.manual_seed(0)
@@ -172,7 +200,15 @@ def main():
     gout = torch.ones(N, C, D, device=device)
 
     segments = None
-    if world > 1 or args.segments:
+    if part_b:
+        sl = sharded.DstPartitionedEGCL(layer)
+        plan = sl.plan(ei, N)
+        ea = ea[plan.edge_ids].contiguous()
+
+        def step():
+            y = sl(h, plan, ea, na)
+            return torch.autograd.grad(y, [h] + params, gout)
+    elif world > 1 or args.segments:
         sl = sharded.ShardedEGCL(layer)
         plan = sl.plan(ei, N)
 
@@ -194,7 +230,7 @@ def main():
     if (world > 1 or args.segments) and not args.no_graph:
         # compute stages as two HIP graphs, the two collectives eager between them
         try:
-            segments = sharded.GraphedShardedStep(sl, plan, h, ea, na, gout)
+            segments = (sharded.GraphedDstStep if part_b else sharded.GraphedShardedStep)(sl, plan, h, ea, na, gout)
             segments.run()
             torch.cuda.synchronize()
         except Exception as exc:
@@ -233,6 +269,24 @@ def main():
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = E_total * args.steps / elapsed
+    # N > 1, partitioning B: the same steps without the collectives (compute-only rate, bus bandwidth)
+    compute_only = None
+    if part_b and segments is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            segments.run(compute_only=True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tc = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        tc = float(tc.item())
+        coll_s = max(elapsed - tc, 1e-9) / args.steps
+        compute_only = {"value": round(E_total * args.steps / tc, 1), "ms_per_step": round(1e3 * tc / args.steps, 4),
+                        "collective_ms_per_step": round(1e3 * coll_s, 4),
+                        "bytes_sent_per_rank_per_step": segments.bytes_per_step,
+                        "bus_GBps_per_rank": round(segments.bytes_per_step / coll_s / 1e9, 2)}
 
     result = None
     if rank == 0:
@@ -240,6 +294,7 @@ def main():
         be = ops.HipBackend
         spec = layer.spec()
         csr = ops.get_csr(ei, N) if world == 1 else plan.csr
+        csr_build_ms = getattr(csr, "build_ms", None)
         deg = csr.deg if world == 1 else plan.deg
         pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
         hd = h.detach()
@@ -271,8 +326,9 @@ def main():
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
         bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
         roofline = {
-            "bound": "hbm", "kernel": f"cemlp_kernel<{dom}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom),
+            "bound": "hbm", "kernel": f"{dom} (cemlp_rl_kernel when the layer is 8 channels of Cl(3,0), else cemlp_kernel / cemlp_ps_kernel)",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload),
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "layer_bytes_per_edge": round(bytes_per_edge, 1),
@@ -282,15 +338,22 @@ def main():
             "metric": "simplicial edges/sec (fwd+bwd) on Cl(3,0) 8-ch multivectors; % HBM roofline"
                       if args.workload == "S1" else f"simplicial edges/sec (fwd+bwd), workload {args.workload}",
             "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: EGCL layer fwd+bwd, Cl{tuple(int(m) for m in metric)}, "
-                                   f"{C} channels, {N} nodes, {E_per} edges/GPU x {world} GPU, aggr=mean, "
-                                   f"edge_attr 6ch, node_attr 3ch",
+                                   f"{C} channels, {N} nodes, "
+                                   + (f"{E_per} edges/GPU x {world} GPU" if args.scaling == "weak" else
+                                      f"{E_total} edges sharded over {world} GPU")
+                                   + ", aggr=mean, edge_attr 6ch, node_attr 3ch",
+                       "csr_build_ms": None if csr_build_ms is None else round(csr_build_ms, 3),
+                       "host_cores": os.cpu_count(),
                        "launch": ("hip-graph replay" if graph is not None else
                                   "hip-graph segments + eager collectives" if segments is not None else "eager"),
-                       "sharding": "edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"
-                                   if world > 1 else "none"},
+                       "sharding": ("none" if world == 1 else
+                                    "B: nodes partitioned, edges by target; all-gather(out) fwd, reduce-scatter(d/dh) + "
+                                    "all-reduce(param grads) bwd" if part_b else
+                                    "A: edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"),
+                       "compute_only": compute_only},
             "roofline": roofline,
         }
     if world > 1:

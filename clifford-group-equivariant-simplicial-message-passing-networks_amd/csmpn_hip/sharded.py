@@ -16,6 +16,15 @@ csmpn/md17.py:15-20); this is the partitioning BASELINE.json's north_star names:
 The data path of a shard has no other exchange step. The compute backend is
 injectable so that the collective plumbing is testable on CPU with gloo (tests
 inject the oracle there); the default backend is the HIP C-ABI.
+
+Partitioning B (`DstPartitionedEGCL`): rank r owns the nodes
+[r N/W, (r+1) N/W) and ALL edges into them. Its aggregate is complete without any
+reduction and the node update runs on its own nodes only, so nothing is computed
+twice (partitioning A replicates the node update: an Amdahl bound of ~4x at 8 GPUs
+with the S2 stage times). Exchanges per layer: forward ONE all-gather of the updated
+node slices, backward ONE reduce-scatter of d/dh (the -g -> source half lands on any
+node) plus an all-reduce of the parameter gradients (a few thousand floats) - half
+the bytes of A, and both collectives use all xGMI links at once.
 """
 from __future__ import annotations
 
@@ -157,7 +166,11 @@ class GraphedShardedStep:
                 and os.environ.get("CSMPN_SPLIT_FWD", "1") != "0"):
             n_half = plan.n_nodes // 2
             e1 = int(plan.csr.row_ptr[n_half].item())
-            if 0 < e1 < plan.csr.n_edges:
+            # the choice changes which collectives a rank issues (two half-size all-reduces or one
+            # whole one): it must be the same on every rank - split only if EVERY shard straddles N/2
+            can = torch.tensor([1 if 0 < e1 < plan.csr.n_edges else 0], dtype=torch.int32, device=h.device)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN, group=self.group)
+            if int(can.item()) == 1:
                 self._split = (n_half, e1)
 
         def part1():
@@ -246,3 +259,223 @@ class GraphedShardedStep:
                 views_e.append(self.packed[off:off + cnt].view(shp))
                 off += cnt
         return self.out, self.gh, views_e, list(self.views_n)
+
+
+# ===================================================================================== partitioning B
+
+
+def node_bounds(n_nodes: int, world: int, rank: int):
+    """Equal node slices (reduce-scatter / all-gather need equal sizes): N must divide by the world size."""
+    if n_nodes % world:
+        raise ValueError(f"partitioning B needs n_nodes ({n_nodes}) divisible by the world size ({world})")
+    per = n_nodes // world
+    return rank * per, (rank + 1) * per
+
+
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _all_gather_rows(full, part, group):
+    """full[W * n] <- concat over ranks of part[n] (rows)."""
+    try:
+        dist.all_gather_into_tensor(full, part, group=group)
+    except (RuntimeError, NotImplementedError):   # backends without the fused form (gloo on old builds)
+        chunks = list(full.chunk(dist.get_world_size(group), dim=0))
+        dist.all_gather(chunks, part, group=group)
+
+
+def _reduce_scatter_rows(part, full, group):
+    """part[n] <- this rank's row slice of the sum over ranks of full[W * n]."""
+    try:
+        dist.reduce_scatter_tensor(part, full, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):   # gloo has no reduce-scatter: all-reduce and slice
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        w, r = dist.get_world_size(group), dist.get_rank(group)
+        part.copy_(full.chunk(w, dim=0)[r])
+
+
+class DstPlan:
+    """Per-complex state of one rank for partitioning B: the edges into its node slice (global node
+    ids), their ids in the caller's edge order (for edge_attr), and the slice bounds."""
+
+    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None):
+        self.world, self.rank = _world(group)
+        self.lo, self.hi = node_bounds(n_nodes, self.world, self.rank)
+        dst = edge_index[1]
+        mine = (dst >= self.lo) & (dst < self.hi)
+        self.edge_ids = torch.nonzero(mine, as_tuple=False).squeeze(1)
+        self.csr = backend.build_csr(edge_index[:, self.edge_ids].contiguous(), n_nodes)
+        self.deg = self.csr.deg     # every edge into an owned node is local: the local in-degree is the global one
+        self.n_nodes = n_nodes
+
+
+class _DstPartEgclFn(torch.autograd.Function):
+    """h [N, C, D] replicated in; out [N, C, D] replicated out (all-gathered); gradients w.r.t. h
+    come back replicated as well (reduce-scatter + all-gather of the slices), so the layer composes
+    like the unsharded one."""
+
+    @staticmethod
+    def forward(ctx, h, edge_attr_local, node_attr, spec, plan: DstPlan, backend, group, *params):
+        h = h.contiguous()
+        ne = spec.edge.nblk * ops.NP
+        pe, pn = params[:ne], params[ne:]
+        lo, hi = plan.lo, plan.hi
+        agg, st_e = backend.edge_forward(spec, plan.csr, h, edge_attr_local, pe)      # complete on [lo, hi)
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        out_loc, st_n = backend.node_forward(spec, plan.deg[lo:hi].contiguous(), h[lo:hi].contiguous(),
+                                             agg[lo:hi].contiguous(), na_loc, pn)
+        if plan.world > 1:
+            out = torch.empty_like(h) if out_loc.shape[1:] == h.shape[1:] else \
+                torch.empty((h.shape[0],) + tuple(out_loc.shape[1:]), dtype=h.dtype, device=h.device)
+            _all_gather_rows(out, out_loc.contiguous(), group)
+        else:
+            out = out_loc
+        ctx.st_e, ctx.st_n = st_e, st_n
+        ctx.spec, ctx.plan, ctx.backend, ctx.group = spec, plan, backend, group
+        ctx.has_ea, ctx.has_na = edge_attr_local is not None, node_attr is not None
+        ctx.mask = [p is not None for p in params]
+        saved = [h, agg] + ([edge_attr_local] if ctx.has_ea else []) + ([node_attr] if ctx.has_na else [])
+        ctx.save_for_backward(*saved, *[p for p in params if p is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        spec, plan, backend, group = ctx.spec, ctx.plan, ctx.backend, ctx.group
+        saved = list(ctx.saved_tensors)
+        h, agg = saved[0], saved[1]
+        pos = 2
+        edge_attr = node_attr = None
+        if ctx.has_ea:
+            edge_attr = saved[pos]; pos += 1
+        if ctx.has_na:
+            node_attr = saved[pos]; pos += 1
+        it = iter(saved[pos:])
+        params = [next(it) if m else None for m in ctx.mask]
+        ne = spec.edge.nblk * ops.NP
+        pe, pn = params[:ne], params[ne:]
+        lo, hi = plan.lo, plan.hi
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        gh_node, g_agg_loc, g_na_loc, views_n = backend.node_backward(
+            spec, plan.deg[lo:hi].contiguous(), h[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn,
+            gout[lo:hi].contiguous(), ctx.needs_input_grad[2], ctx.st_n)
+        g_agg = torch.zeros_like(agg)
+        g_agg[lo:hi] = g_agg_loc
+        gh_edge = torch.zeros_like(h)          # +g -> owned targets, -g -> any source
+        g_ea, views_e = backend.edge_backward(spec, plan.csr, h, edge_attr, pe, g_agg, gh_edge,
+                                              ctx.needs_input_grad[1], ctx.st_e)
+        views = list(views_e) + list(views_n)
+        if plan.world > 1:
+            gh_loc = torch.empty_like(gh_node)
+            _reduce_scatter_rows(gh_loc, gh_edge, group)
+            gh_loc += gh_node
+            gh = torch.empty_like(h)
+            _all_gather_rows(gh, gh_loc, group)
+            flat = torch.cat([v.reshape(-1) for v in views if v is not None])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off, red = 0, []
+            for v in views:
+                if v is None:
+                    red.append(None)
+                else:
+                    red.append(flat[off:off + v.numel()].view(v.shape))
+                    off += v.numel()
+            views = red
+            g_na = None
+            if g_na_loc is not None:
+                g_na = torch.zeros_like(node_attr)
+                g_na[lo:hi] = g_na_loc
+                dist.all_reduce(g_na, op=dist.ReduceOp.SUM, group=group)
+        else:
+            gh = gh_edge
+            gh[lo:hi] += gh_node
+            g_na = g_na_loc
+        return (gh, g_ea, g_na, None, None, None, None, *views)
+
+
+class DstPartitionedEGCL(torch.nn.Module):
+    """Wraps an EGCL module (partitioning B). `plan(edge_index, n_nodes)` takes the WHOLE edge list
+    (replicated topology); forward takes the whole h / node_attr and this rank's rows of edge_attr
+    (`edge_attr[plan.edge_ids]`)."""
+
+    def __init__(self, layer, backend=ops.HipBackend, group=None):
+        super().__init__()
+        self.layer = layer
+        self.backend = backend
+        self.group = group
+
+    def plan(self, edge_index, n_nodes) -> DstPlan:
+        return DstPlan(edge_index, n_nodes, self.backend, self.group)
+
+    def forward(self, h, plan: DstPlan, edge_attr_local=None, node_attr=None):
+        layer = self.layer
+        params = layer.edge_model.flat_params() + layer.node_model.flat_params()
+        return _DstPartEgclFn.apply(h, edge_attr_local, node_attr, layer.spec(), plan, self.backend, self.group,
+                                    *params)
+
+
+class GraphedDstStep:
+    """Forward + backward of the destination-partitioned layer on fixed buffers (multi-GPU benchmark):
+    [graph 1: edge forward on the owned targets, node forward on the owned nodes] -> all-gather(out)
+    -> [graph 2: node backward, edge backward] -> reduce-scatter(d/dh) + all-reduce(parameter
+    gradients). `compute_only=True` skips the collectives (the compute-only rate of the bench)."""
+
+    def __init__(self, part: "DstPartitionedEGCL", plan: DstPlan, h, edge_attr_local, node_attr, gout):
+        layer, be = part.layer, part.backend
+        self.group, self.plan = part.group, plan
+        self.spec = spec = layer.spec()
+        pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+        self.h = h_ = h.detach()
+        lo, hi = plan.lo, plan.hi
+        self._multi = plan.world > 1
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        h_loc, deg_loc, gout_loc = h_[lo:hi], plan.deg[lo:hi].contiguous(), gout[lo:hi].contiguous()
+        self.out = torch.empty_like(h_)
+        self.gh = torch.empty_like(h_)
+
+        def part1():
+            agg, st_e = be.edge_forward(spec, plan.csr, h_, edge_attr_local, pe)
+            out_loc, st_n = be.node_forward(spec, deg_loc, h_loc, agg[lo:hi], na_loc, pn)
+            return agg, st_e, out_loc, st_n
+
+        def part2(agg, st_e, st_n):
+            gh_node, g_agg_loc, _g, views_n = be.node_backward(spec, deg_loc, h_loc, agg[lo:hi], na_loc, pn, gout_loc, False, st_n)
+            g_agg = torch.zeros_like(agg)
+            g_agg[lo:hi] = g_agg_loc
+            gh_edge = torch.zeros_like(h_)
+            _g_ea, views_e = be.edge_backward(spec, plan.csr, h_, edge_attr_local, pe, g_agg, gh_edge, False, st_e)
+            flat = torch.cat([v.reshape(-1) for v in list(views_e) + list(views_n) if v is not None])
+            return gh_node, gh_edge, flat
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            a, se, ol, sn = part1()
+            part2(a, se, sn)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
+            self.agg, self._st_e, self.out_loc, self._st_n = part1()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
+            self.gh_node, self.gh_edge, self.flat = part2(self.agg, self._st_e, self._st_n)
+        self.gh_loc = torch.empty_like(self.gh_node)
+        self.bytes_per_step = 0
+        if self._multi:
+            w = plan.world
+            # bytes every rank sends per step: all-gather and reduce-scatter move (W-1)/W of the tensor
+            self.bytes_per_step = int(2 * h_.numel() * 4 * (w - 1) / w + 2 * self.flat.numel() * 4 * (w - 1) / w)
+
+    def run(self, compute_only=False):
+        self.g1.replay()
+        if self._multi and not compute_only:
+            _all_gather_rows(self.out, self.out_loc, self.group)
+        self.g2.replay()
+        if self._multi and not compute_only:
+            _reduce_scatter_rows(self.gh_loc, self.gh_edge, self.group)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.gh_loc += self.gh_node
+        else:
+            torch.add(self.gh_edge[self.plan.lo:self.plan.hi], self.gh_node, out=self.gh_loc)

@@ -94,3 +94,73 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ----------------------------------------------------------------------------- partitioning B
+
+def _worker_dst(rank, world, port, aggr, q):
+    """Destination-partitioned layer: every rank owns N/W nodes and all edges into
+    them; all-gather of the output slices forward, reduce-scatter of d/dh backward."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        from oracle import ref_path as O
+        from oracle_backend import OracleBackend
+        torch.manual_seed(0)
+        alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+        layer = pkg.EGCL(alg, 4, 5, 4, edge_attr_features=6, node_attr_features=3, aggr=aggr)
+        o = O.Algebra([1.0, 1.0, 1.0])
+        N, E = 12 * world, 401
+        h, ei, ea, na = O.synthetic_complex(o, N, E, 4, seed=1)
+        ei[1, :40] = 3                       # a hub inside rank 0's slice: unbalanced edge counts
+        gout = torch.randn(N, 4, 8, generator=torch.Generator().manual_seed(2))
+        part = sharded.DstPartitionedEGCL(layer, backend=OracleBackend)
+        plan = part.plan(ei, N)
+        assert plan.hi - plan.lo == N // world
+        hh = h.clone().requires_grad_(True)
+        eal = ea[plan.edge_ids].clone().requires_grad_(True)
+        naa = na.clone().requires_grad_(True)
+        y = part(hh, plan, eal, naa)
+        y.backward(gout)
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in layer.named_parameters()}
+        h2 = h.clone().requires_grad_(True)
+        ea2 = ea.clone().requires_grad_(True)
+        na2 = na.clone().requires_grad_(True)
+        y2 = O.egcl(o, h2, ei, ea2, na2, p, aggr=aggr)
+        y2.backward(gout)
+        # every edge belongs to exactly one rank
+        cnt = torch.zeros(E)
+        cnt[plan.edge_ids] = 1
+        dist.all_reduce(cnt)
+        res = {"y": (y.detach() - y2.detach()).abs().max().item(),
+               "gh": (hh.grad - h2.grad).abs().max().item(),
+               "gea": (eal.grad - ea2.grad[plan.edge_ids]).abs().max().item(),
+               "gna": (naa.grad - na2.grad).abs().max().item(),
+               "cover": float((cnt - 1).abs().max())}
+        for k, prm in layer.named_parameters():
+            res["g." + k] = (prm.grad - p[k].grad).abs().max().item() / max(p[k].grad.abs().max().item(), 1e-6)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("aggr,world", [("mean", 2), ("sum", 3)])
+def test_dst_partitioned_matches_unsharded(aggr, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dst, args=(r, world, port, aggr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert res["cover"] == 0
+        for k, v in res.items():
+            assert v < 5e-5, (rank, k, v)

@@ -85,3 +85,62 @@ def test_sharded_hip_matches_unsharded():
         assert res["deg"] == 0
         for k, v in res.items():
             assert v < 2e-5, (rank, k, v)
+
+
+def _worker_dst(rank, world, port, q):
+    """Partitioning B with the HIP backend: nodes partitioned, edges by target."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        from oracle import ref_path as O
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+        layer = pkg.EGCL(alg, 8, 8, 8, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
+        N, E = 500, 7001
+        h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), N, E, 8, seed=1))
+        gout = torch.randn(N, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+        part = sharded.DstPartitionedEGCL(layer)
+        plan = part.plan(ei, N)
+        eal = ea[plan.edge_ids].contiguous()
+        hh = h.clone().requires_grad_(True)
+        y = part(hh, plan, eal, na)
+        params = list(layer.parameters())
+        gs = torch.autograd.grad(y, [hh] + params, gout)
+        h2 = h.clone().requires_grad_(True)
+        y2 = layer(h2, ei, ea, na)
+        g2 = torch.autograd.grad(y2, [h2] + params, gout)
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        res = {"y": rel(y, y2)}
+        for i, (a, b) in enumerate(zip(gs, g2)):
+            res[f"g{i}"] = rel(a, b)
+        st = sharded.GraphedDstStep(part, plan, h, eal, na, gout)
+        for _ in range(2):
+            st.run()
+        torch.cuda.synchronize()
+        lo, hi = plan.lo, plan.hi
+        res["graph.y"] = rel(st.out, y2.detach())
+        res["graph.gh"] = rel(st.gh_loc, g2[0][lo:hi])
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dst_partitioned_hip_matches_unsharded():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dst, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, res in results:
+        for k, v in res.items():
+            assert v < 2e-5, (rank, k, v)
