@@ -11,8 +11,8 @@ each with: the batch tensors, the model's state_dict (float32), loss / per-graph
 and a float64 run (same parameters), and for every parameter the norm of its gradient and the
 gradient's dot product with a seeded Gaussian direction (both runs) plus, for parameters of at most
 1024 elements, the whole float64 gradient;
-  traj_hulls.npz    the 20-step Adam (lr 1e-3) loss trajectory of the hulls model over two
-                    alternating 4-graph batches (the "matching reference MSE" proxy: the real
+  traj_hulls.npz    the 20-step Adam (lr 1e-3) loss trajectory of the hulls model (starting from
+                    model_hulls.npz's parameters) over two alternating 4-graph batches (the "matching reference MSE" proxy: the real
                     dataset needs gudhi / DATAROOT).
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
 loaded by file path so that the reference's `csmpn` namespace stays in front).
@@ -53,7 +53,7 @@ BIG = 1024
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()   # a copy: .numpy() aliases the (later updated) parameter
 
 
 def namespace(batch, dtype):
@@ -155,11 +155,10 @@ def make_hulls():
     b2 = hulls_batch(8)
     save_batch(tr, batch, "b0/")
     save_batch(tr, b2, "b1/")
+    # same seed as the model fixture above: the trajectory starts from model_hulls.npz's parameters
+    # (step 0 reproduces its loss; checked below), so they are not stored a second time
     torch.manual_seed(101)
     model = HullsCliffordSharedSimplicialMPNN()
-    for k, v in model.state_dict().items():
-        if "algebra." not in k:
-            tr[f"p/{k}"] = npy(v)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     losses = []
     for step in range(20):
@@ -170,6 +169,7 @@ def make_hulls():
         opt.step()
         losses.append(float(loss))
         print("traj step", step, losses[-1], flush=True)
+    assert abs(losses[0] - float(out["f32/backprop_loss"])) <= 1e-6 * abs(losses[0])
     tr["losses"] = np.asarray(losses, dtype=np.float64)
     np.savez_compressed(os.path.join(HERE, "traj_hulls.npz"), **tr)
 

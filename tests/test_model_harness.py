@@ -193,7 +193,7 @@ def test_hulls_adam_trajectory_gpu(pkg):
     needs gudhi / DATAROOT)."""
     dev = torch.device("cuda:0")
     g = np.load(os.path.join(GOLD, "traj_hulls.npz"))
-    model = build(pkg, "hulls", g, dev)
+    model = build(pkg, "hulls", np.load(os.path.join(GOLD, "model_hulls.npz")), dev)   # the trajectory's start
     batches = [load_batch(pkg, g, "b0/", dev), load_batch(pkg, g, "b1/", dev)]
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     ref = g["losses"]
@@ -203,7 +203,7 @@ def test_hulls_adam_trajectory_gpu(pkg):
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        got.append(float(loss))
+        got.append(float(loss.detach()))
     got = np.asarray(got)
     # float32 training diverges slowly between two correct implementations: 1e-5 on the first
     # step, a budget growing to 2e-3 over 20 steps
