@@ -136,7 +136,26 @@ def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0):
     ne = int(min(ei.shape[1], max(probe_e, probe_e * budget_s / (reps * max(t_probe, 1e-4)))))
     times = [run(ne) for _ in range(reps)]
     med = statistics.median(times)
+    twin = None
+    try:   # the C++ sparse-formulation twin (oracle/cpu_twin): the strong CPU baseline, all host cores
+        from oracle import cpu_twin
+        pn = {k: v.detach().cpu().numpy() for k, v in state.items()}
+        gout = torch.ones(h.shape[0], C, 1 << len(metric)).numpy()
+        args_t = (list(metric), pn, h.numpy(), ei.numpy(), ea.numpy(), na.numpy())
+        cpu_twin.egcl_layer(*args_t, aggr="mean", gout=gout)
+        tt = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            cpu_twin.egcl_layer(*args_t, aggr="mean", gout=gout)
+            tt.append(time.perf_counter() - t0)
+        tm = statistics.median(tt)
+        twin = {"value": ei.shape[1] / tm, "unit": "edges/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": f"C++/OpenMP twin (sparse sign-table formulation, oracle/cpu_twin), all {ei.shape[1]} edges, "
+                          f"fwd+bwd, median of 5 runs ({tm:.3f} s each), {os.cpu_count()} threads"}
+    except Exception as exc:   # the twin is optional infrastructure
+        twin = {"error": f"{type(exc).__name__}: {exc}"}
     return {"value": ne / med, "unit": "edges/s", "cores": cores, "kind": "port", "host_cores": os.cpu_count(),
+            "strong_cpu_twin": twin,
             "sample": f"{'all' if ne == ei.shape[1] else 'first'} {ne} of {ei.shape[1]} edges over the same "
                       f"{h.shape[0]} nodes, fwd+bwd, median of {reps} runs ({med:.3f} s each), torch "
                       f"{torch.__version__} CPU threads={cores} of {os.cpu_count()} host cores"}

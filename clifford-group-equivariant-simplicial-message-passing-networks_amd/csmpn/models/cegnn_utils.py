@@ -205,6 +205,13 @@ class CEMLP(nn.Module):
         self._widths = widths
         self._binding = None
 
+    def __getstate__(self):
+        # the cached ctypes binding holds raw pointers: never copied / pickled (deepcopy, torch.save of the
+        # module, EMA / best-model snapshots); it is rebuilt on the next forward
+        state = self.__dict__.copy()
+        state["_binding"] = None
+        return state
+
     def binding(self) -> "ops.CemlpBinding":
         if self._binding is None:
             specs = [dict(in_features=i, out_features=o, lin_subspaces=True) for i, o in self._widths]
@@ -241,6 +248,11 @@ class EGCL(nn.Module):
                                 out_features, normalization_init=normalization_init)
         self.algebra = algebra
         self._spec = None
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_spec"] = None   # holds ctypes bindings (see CEMLP.__getstate__)
+        return state
 
     def spec(self) -> "ops.EgclSpec":
         if self._spec is None:

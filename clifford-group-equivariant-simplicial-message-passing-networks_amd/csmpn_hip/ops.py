@@ -21,6 +21,24 @@ def _stream(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+def _on_device_of(arg_index):
+    """Decorator: run the function with the device of its `arg_index`-th argument current (kernel
+    attributes, launches and the stream belong to that device; the caller's current device may be
+    another one)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*args, **kwargs):
+            t = args[arg_index]
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                with torch.cuda.device(t.device):
+                    return fn(*args, **kwargs)
+            return fn(*args, **kwargs)
+        return wrapped
+    return deco
+
+
 def _require_device(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError(
@@ -138,6 +156,7 @@ class CemlpBinding:
 
 class _CemlpFn(torch.autograd.Function):
     @staticmethod
+    @_on_device_of(1)
     def forward(ctx, x, binding: CemlpBinding, *params):
         _require_device(x, "CEMLP input")
         if x.dim() != 3 or x.shape[1] != binding.in_features or x.shape[2] != binding.D:
@@ -158,6 +177,7 @@ class _CemlpFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_device_of(1)
     def backward(ctx, gy):
         binding = ctx.binding
         x, *present = ctx.saved_tensors
@@ -266,6 +286,7 @@ class HipBackend:
         return get_csr(edge_index, n_nodes)
 
     @staticmethod
+    @_on_device_of(2)
     def edge_forward(spec, csr, h, edge_attr, pe, save=True, agg=None, saved=None):
         """Returns (agg, state); state = (workspace with packed weights, saved block inputs).
         agg: optional [N, O, D] buffer to accumulate into (zeroed by the caller); saved: optional
@@ -285,6 +306,7 @@ class HipBackend:
         return agg, (ws, saved)
 
     @staticmethod
+    @_on_device_of(2)
     def node_forward(spec, deg, h, agg, node_attr, pn, save=True):
         nd = spec.node
         nd.bind(pn)
@@ -299,6 +321,7 @@ class HipBackend:
         return out, (ws, saved)
 
     @staticmethod
+    @_on_device_of(2)
     def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None, gflat=None):
         """state: the workspace node_forward returned (its packed weights are reused);
         gflat: optional zeroed flat gradient buffer (CemlpBinding.grad_floats elements)."""
@@ -318,6 +341,7 @@ class HipBackend:
         return gh, g_agg, g_na, views
 
     @staticmethod
+    @_on_device_of(2)
     def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None, gflat=None):
         """gh is accumulated in place (+= scatter of +-d/d(h_i - h_j)); gflat as in node_backward."""
         e = spec.edge
@@ -415,6 +439,7 @@ def egcl_apply(h, edge_attr, node_attr, spec: EgclSpec, csr: Csr, params):
 
 class _GpFn(torch.autograd.Function):
     @staticmethod
+    @_on_device_of(1)
     def forward(ctx, a, b, metric):
         _require_device(a, "geometric_product operand")
         _require_device(b, "geometric_product operand")
@@ -432,6 +457,7 @@ class _GpFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_on_device_of(1)
     def backward(ctx, gout):
         a2, b2 = ctx.saved_tensors
         metric = ctx.metric
@@ -454,8 +480,12 @@ class _MVLinearFn(torch.autograd.Function):
     (cegnn_utils.py:326-338), for the MVLinear calls outside a CEMLP."""
 
     @staticmethod
+    @_on_device_of(1)
     def forward(ctx, x, weight, bias, n):
         _require_device(x, "MVLinear input")
+        for name, t in (("weight", weight), ("bias", bias)):
+            if t is not None and (t.device != x.device or t.dtype != torch.float32):
+                raise RuntimeError(f"MVLinear {name} must be float32 on {x.device}, got {t.dtype} on {t.device}")
         x = x.contiguous()
         w = weight.contiguous()
         b = bias.contiguous() if bias is not None else None
@@ -471,13 +501,14 @@ class _MVLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_on_device_of(1)
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         rows, I, D = x.shape
         O = w.shape[0]
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None
+        gw = torch.zeros_like(w) if ctx.needs_input_grad[1] else None   # None: frozen weight (bias still gets its gradient)
         gb = torch.zeros(1, O, 1, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         check(native.lib().csmpn_mvlinear_backward(ctx.n, x.data_ptr(), w.data_ptr(), gy.data_ptr(), rows, I, O,
                                                    1 if w.dim() == 3 else 0, _ptr(gx), _ptr(gw), _ptr(gb),

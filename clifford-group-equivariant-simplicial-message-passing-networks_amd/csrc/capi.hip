@@ -636,6 +636,7 @@ __global__ void mvlinear_bwd_w_kernel(const MvLinDesc P) {
     for (int e = threadIdx.x; e < nw + P.O; e += blockDim.x) {
         float acc = 0.f;
         if (e < nw) {
+            if (!P.gw) continue;
             const int g = e % ws, i = (e / ws) % P.I, o = e / (ws * P.I);
             for (long r = r0; r < r1; ++r) {
                 const float* gr = P.gy + (r * P.O + o) * P.D;
@@ -643,7 +644,7 @@ __global__ void mvlinear_bwd_w_kernel(const MvLinDesc P) {
                 for (int d = 0; d < P.D; ++d)
                     if (!P.sub || P.grade[d] == g) acc = fmaf(gr[d], xr[d], acc);
             }
-            atomicAdd(P.gw + e, acc);
+            if (P.gw) atomicAdd(P.gw + e, acc);
         } else if (P.gb) {
             const int o = e - nw;
             for (long r = r0; r < r1; ++r) acc += P.gy[(r * P.O + o) * P.D];
@@ -846,7 +847,7 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
         hipLaunchKernelGGL(mvlinear_bwd_x_kernel, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0,
                            (hipStream_t)stream, P);
     }
-    if (g_weight) {
+    if (g_weight || g_bias) {   // the bias gradient comes from the same kernel: a frozen weight must not silence it
         const unsigned grid = (unsigned)((rows + kMvLinSlab - 1) / kMvLinSlab);
         hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
     }

@@ -111,3 +111,21 @@ def test_unsupported_configs_fail_loudly(pkg):
     assert not b.supported()
     with pytest.raises(native.CsmpnError):
         ops.EgclSpec(None, None, 1, 1, 0, 0, "max", True)
+
+
+def test_modules_copy_and_pickle_after_binding(pkg):
+    """The cached ctypes bindings (raw pointers) must not break deepcopy / torch.save of a module
+    that has already run (EMA, best-model snapshots): they are dropped and rebuilt on demand."""
+    import copy
+    import io
+    layer = pkg.EGCL(pkg.CliffordAlgebra((1.0, 1.0, 1.0)), 4, 4, 4, edge_attr_features=6, node_attr_features=3)
+    layer.spec()
+    layer.edge_model.binding()
+    clone = copy.deepcopy(layer)
+    assert clone._spec is None and clone.edge_model._binding is None
+    assert clone.spec() is not None
+    buf = io.BytesIO()
+    torch.save(layer, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert sorted(back.state_dict()) == sorted(layer.state_dict())

@@ -162,6 +162,18 @@ def test_mvlinear_standalone_large(pkg):
     check("big.gb", m.bias.grad.cpu().numpy(), b64.grad.numpy())
 
 
+def test_mvlinear_frozen_weight_still_gets_bias_grad(pkg):
+    """csmpn_mvlinear_backward with g_weight = NULL: the bias gradient comes from the same kernel."""
+    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+    m = pkg.MVLinear(alg, 5, 3).to(dev())
+    m.weight.requires_grad_(False)
+    x = torch.randn(333, 5, 8, device=dev())
+    gout = torch.randn(333, 3, 8, device=dev())
+    (m(x) * gout).sum().backward()
+    assert m.weight.grad is None
+    check("gb", m.bias.grad.cpu().numpy().reshape(-1), gout[:, :, 0].sum(0).cpu().numpy())
+
+
 EGCL_TAGS = ["sum_res1_ag0", "sum_res1_ag1", "sum_res0_ag0", "mean_res1_ag0", "mean_res1_ag1", "mean_res0_ag0", "noattr"]
 
 
