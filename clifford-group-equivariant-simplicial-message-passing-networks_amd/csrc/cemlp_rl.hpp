@@ -54,14 +54,25 @@ template <class ALG, int NOG, int NBLK, int I0>
 struct RlLay {
     static constexpr int C = 4 * NOG, D = ALG::D, G = ALG::G, P = ALG::P, R = 64 / NOG;
     static constexpr int IM = I0 > C ? I0 : C;
-    static constexpr int WS = 4 * (IM | 1);          // weight row stride: odd number of 16-byte slots
-    // parameter store of one block: three weight matrices [C][WS] in the reference's [o][c][g]
-    // order (g padded to 4), then the per-channel parameters channel-fastest
-    static constexpr int sW1 = 0, sWR = sW1 + C * WS, sWL = sWR + C * WS;
-    static constexpr int sb1 = sWL + C * WS, sbL = sb1 + C, sla = sbL + C;
-    static constexpr int ssa = sla + C, ssb = ssa + C * G, ssg = ssb + C * G, sw = ssg + C * G;   // [g][C] ; w [p][C]
-    static constexpr int store_total = sw + C * P;
-    static constexpr int st_off(int k) { return k * store_total; }
+    // weight row strides (floats): an odd number of 16-byte slots (conflict-free broadcast reads);
+    // WS1 for block 0's MVLinear [C][I0], WSC for every C x C matrix
+    static constexpr int WS1 = 4 * (I0 | 1), WSC = 4 * (C | 1);
+    static constexpr int wstride(int k) { return k == 0 ? WS1 : WSC; }
+    // parameter store of block k: W1 [C][wstride(k)], WR, WL [C][WSC] in the reference's [o][c][g]
+    // order (g padded to 4), then the per-channel parameters channel-fastest ([g][C]; w [p][C])
+    static constexpr int store_total(int k) { return C * wstride(k) + 2 * C * WSC + C * (3 + 3 * G + P); }
+    static constexpr int st_off(int k) { return k == 0 ? 0 : store_total(0); }
+    static constexpr int store_all = store_total(0) + (NBLK > 1 ? store_total(1) : 0);
+    static constexpr int o_W1(int k) { return st_off(k); }
+    static constexpr int o_WR(int k) { return o_W1(k) + C * wstride(k); }
+    static constexpr int o_WL(int k) { return o_WR(k) + C * WSC; }
+    static constexpr int o_b1(int k) { return o_WL(k) + C * WSC; }
+    static constexpr int o_bL(int k) { return o_b1(k) + C; }
+    static constexpr int o_la(int k) { return o_bL(k) + C; }
+    static constexpr int o_sa(int k) { return o_la(k) + C; }
+    static constexpr int o_sb(int k) { return o_sa(k) + C * G; }
+    static constexpr int o_sg(int k) { return o_sb(k) + C * G; }
+    static constexpr int o_w(int k) { return o_sg(k) + C * G; }
     static constexpr int Iof(int k) { return k == 0 ? I0 : C; }
     // partial-buffer slice of one wave: per block [W1 [C][I][G] | WR [C][C][G] | WL | small], reference
     // layouts; small = b1 [C], sa [C][G], sb [C][G], w [C][P], an [C][G], bL [C], la [C]
@@ -80,18 +91,22 @@ struct RlLay {
     static constexpr int RS = R + 4;                 // row stride of a transposition slice
     static constexpr int SS = C * D + 4;             // row stride of the staging tile
     static constexpr int stage_floats = R * SS;
-    static constexpr int slice_floats = (16 + (I0 > 16 ? 32 : 16)) * RS;
+    static constexpr int MA_RL = C / 8;              // A tiles (16 rows) of the linear_right | linear_left gradient
+    static constexpr int b_off = 16 * MA_RL * RS;    // B slice behind the A rows
+    static constexpr int slice_floats = b_off + (IM + 3) / 4 * 4 * RS;
     static constexpr int red_floats = (8 * 65 + 64) * 4;   // reduction: 8 values x 65 f4 slots, then 64 f4
     // the reduction slots hold pending values while the weight-gradient slices are in use: separate
     // regions; the staging tile (end of the tile pass) may alias both
     static constexpr int red_off = slice_floats;
-    static constexpr int scratch1 = stage_floats > slice_floats + red_floats ? stage_floats : slice_floats + red_floats;
+    static constexpr int cmax(int a, int b) { return a > b ? a : b; }
+    // ... and the image of one block's slice of the partial buffer at the end of the launch
+    static constexpr int scratch1 = cmax(cmax(stage_floats, slice_floats + red_floats), cmax(part_blk(0), NBLK > 1 ? part_blk(1) : 0));
     // running totals of the small-parameter gradients: [block][chunk][lane] f4, read-modify-written by
     // their own lane only (registers are the scarce resource of the backward)
     static constexpr int tot_off = scratch1;
     static constexpr int tot_floats = NBLK * n_chunk * 64 * 4;
     static constexpr int scratch = scratch1 + tot_floats;
-    static constexpr int sc_fwd = NBLK * store_total, sc_bwd = NBLK * store_total;
+    static constexpr int sc_fwd = store_all, sc_bwd = store_all;
     static constexpr int fwd_total(bool edge) { return sc_fwd + (edge ? kRlWaves * stage_floats : 0); }
     static constexpr int bwd_total = sc_bwd + kRlWaves * scratch;
 };
@@ -101,11 +116,11 @@ template <class ALG, int NOG, int NBLK, int I0>
 struct RlGeo {
     static_assert(NOG == 2 || NOG == 4, "2 or 4 lanes per row");
     using LY = RlLay<ALG, NOG, NBLK, I0>;
-    static constexpr int R = LY::R, C = LY::C, WS = LY::WS, RS = LY::RS, G = ALG::G, P = ALG::P;
+    static constexpr int R = LY::R, C = LY::C, WS1 = LY::WS1, WSC = LY::WSC, RS = LY::RS, G = ALG::G, P = ALG::P;
     static constexpr int NGL0 = ((I0 + 3) / 4 + NOG - 1) / NOG;   // input channel groups of block 0 per lane
     int lane, l3, og, r;
-    int a_x;            // forward weight row of this lane: (4og + l3) * WS
-    int a_f[NOG];       // + the 4 input channels of piece k
+    int a_x;            // block 0's MVLinear: weight row of this lane, (4og + l3) * WS1
+    int a_f[NOG];       // C x C matrices: row (4og + l3) * WSC + the 4 input channels of piece k
     int a_t[NOG];       // transposed: rows of piece k's 4 output channels, column of this lane's input channel
     int a_ts[NOG];      // transposed to the gathered input: rows of piece k
     int c_t[NGL0];      // ... column 4 * min(4 (og + NOG t) + l3, I0 - 1)
@@ -144,12 +159,12 @@ struct RlGeo {
         } else {
             src_og[1] = dpp_movi<0x124>(og); src_og[2] = dpp_movi<0x128>(og); src_og[3] = dpp_movi<0x12C>(og);
         }
-        a_x = (4 * og + l3) * WS;
+        a_x = (4 * og + l3) * WS1;
 #pragma unroll
         for (int k = 0; k < NOG; ++k) {
-            a_f[k] = a_x + 16 * src_og[k];
-            a_ts[k] = 4 * src_og[k] * WS;
-            a_t[k] = a_ts[k] + 4 * (4 * og + l3);
+            a_f[k] = (4 * og + l3) * WSC + 16 * src_og[k];
+            a_ts[k] = 4 * src_og[k] * WS1;
+            a_t[k] = 4 * src_og[k] * WSC + 4 * (4 * og + l3);
         }
 #pragma unroll
         for (int t = 0; t < NGL0; ++t) {
@@ -158,8 +173,13 @@ struct RlGeo {
         }
         p_og = 4 * og;
         r_w = LY::red_off + 4 * lane;
-        r_r = LY::red_off + 4 * ((lane & 7) * 65 + (lane & ~7));
-        r_r2 = LY::red_off + 4 * (8 * 65 + (lane & 15));
+        if constexpr (NOG == 2) {   // lane L sums value L & 7 over the 8 lanes (L & ~7) + s: one channel group, one DPP row
+            r_r = LY::red_off + 4 * ((lane & 7) * 65 + (lane & ~7));
+            r_r2 = LY::red_off + 4 * (8 * 65 + (lane & 15));
+        } else {                    // value L & 7, channel group (L >> 3) & 3, rows of the DPP-row pair L >> 5
+            r_r = LY::red_off + 4 * ((lane & 7) * 65 + 32 * (lane >> 5) + 4 * ((lane >> 3) & 3));
+            r_r2 = LY::red_off + 4 * (8 * 65 + (lane & 31));
+        }
         r_t = 4 * lane;
         s_w = 4 * og * RS + r;
         const int m = lane & 15, q = lane >> 4;
@@ -203,35 +223,39 @@ CSMPN_DEV float rl_row_sum(float v) {
 
 // ---------------------------------------------------------------------------------
 // parameters -> LDS store (once per workgroup; all global loads of a thread in flight together)
-template <class LY, int I>
-__device__ void rl_stage_store(const DevBlock& B, float* st, int tid) {
-    constexpr int C = LY::C, G = LY::G, P = LY::P, WS = LY::WS;
-    constexpr int NIT = (LY::store_total + 64 * kRlWaves - 1) / (64 * kRlWaves);
+template <class LY, int K>
+__device__ void rl_stage_store(const DevBlock& B, float* lds, int tid) {
+    constexpr int C = LY::C, G = LY::G, P = LY::P, I = LY::Iof(K), WSa = LY::wstride(K), WSC = LY::WSC;
+    constexpr int total = LY::store_total(K), nW1 = C * WSa, nW = nW1 + 2 * C * WSC;
+    constexpr int NIT = (total + 64 * kRlWaves - 1) / (64 * kRlWaves);
+    float* st = lds + LY::st_off(K);
     float v[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 64 * kRlWaves;
         const float* src = nullptr;
         bool sig = false;
-        if (e < LY::sb1) {
-            const int which = e / (C * WS), f = e - which * (C * WS);
-            const int o = f / WS, r = f - o * WS, c = r >> 2, g = r & 3;
-            const int Iw = which == 0 ? I : C;
-            const float* w = which == 0 ? B.W1 : (which == 1 ? B.WR : B.WL);
-            if (c < Iw && g < G) src = w + (o * Iw + c) * G + g;
-        } else if (e < LY::sbL) {
-            if (B.has_b1) src = B.b1 + (e - LY::sb1);
-        } else if (e < LY::sla) {
-            src = B.bL + (e - LY::sbL);
-        } else if (e < LY::ssa) {
-            src = B.la + (e - LY::sla);
-        } else if (e < LY::sw) {
-            const int f = e - LY::ssa, which = f / (C * G), r = f - which * C * G, g = r / C, o = r - g * C;
-            src = (which == 0 ? B.sa : (which == 1 ? B.sb : B.an)) + o * G + g;
-            sig = which == 2;
-        } else if (e < LY::store_total) {
-            const int f = e - LY::sw, p = f / C, o = f - p * C;
-            src = B.w + o * P + p;
+        if (e < nW1) {
+            const int o = e / WSa, r = e - o * WSa, c = r >> 2, g = r & 3;
+            if (c < I && g < G) src = B.W1 + (o * I + c) * G + g;
+        } else if (e < nW) {
+            const int f0 = e - nW1, which = f0 / (C * WSC), f = f0 - which * (C * WSC);
+            const int o = f / WSC, r = f - o * WSC, c = r >> 2, g = r & 3;
+            if (c < C && g < G) src = (which == 0 ? B.WR : B.WL) + (o * C + c) * G + g;
+        } else if (e < total) {
+            int f = e - nW;
+            if (f < C) { if (B.has_b1) src = B.b1 + f; }
+            else if ((f -= C) < C) src = B.bL + f;
+            else if ((f -= C) < C) src = B.la + f;
+            else if ((f -= C) < 3 * C * G) {
+                const int which = f / (C * G), r = f - which * C * G, g = r / C, o = r - g * C;
+                src = (which == 0 ? B.sa : (which == 1 ? B.sb : B.an)) + o * G + g;
+                sig = which == 2;
+            } else {
+                f -= 3 * C * G;
+                const int p = f / C, o = f - p * C;
+                src = B.w + o * P + p;
+            }
         }
         v[it] = src ? *src : 0.f;
         if (sig) v[it] = sigmoidf(v[it]);
@@ -239,7 +263,7 @@ __device__ void rl_stage_store(const DevBlock& B, float* st, int tid) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 64 * kRlWaves;
-        if (e < LY::store_total) st[e] = v[it];
+        if (e < total) st[e] = v[it];
     }
 }
 
@@ -297,12 +321,13 @@ __global__ void __launch_bounds__(256) rl_reduce_kernel(const DevCemlp C_arg, co
 
 // input: I channels all present in the lane (the row's gathered input)
 //   acc[d] += sum_c W[4og + i][c][grade(d)] * X[c][d]
-template <class ALG, int WOFF, int I, class GE>
-CSMPN_DEV void rl_linear_x(f4 (&acc)[ALG::D], const float (&X)[I][ALG::D], const float* lds, const GE& ge) {
+// (a chunk of them: X = input channels C0 .. C0 + NCH)
+template <class ALG, int WOFF, int C0, int NCH, class GE>
+CSMPN_DEV void rl_linear_x(f4 (&acc)[ALG::D], const float (&X)[NCH][ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D;
     const float* wp = lds + ge.a_x;
-    static_for<0, I>([&](auto c) {
-        const f4 w = ld4(wp + (WOFF + 4 * c));
+    static_for<0, NCH>([&](auto c) {
+        const f4 w = ld4(wp + (WOFF + 4 * (C0 + c)));
         static_for<0, D>([&](auto d) { acc[d] = mfma4(w[ALG::grade(d)], X[c][d], acc[d]); });
     });
 }
@@ -325,7 +350,7 @@ CSMPN_DEV void rl_linear_d(f4 (&acc)[ALG::D], const f4 (&T)[ALG::D], const float
 // transposed, C -> C:  gx[d] (the lane's 4 INPUT channels) += sum_o W[o][4og + i][grade(d)] * Gin[o][d]
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
-    constexpr int D = ALG::D, WS = GE::WS;
+    constexpr int D = ALG::D, WS = GE::WSC;
     static_for<0, NOG>([&](auto k) {
         const float* wp = lds + ge.a_t[k];
         static_for<0, 4>([&](auto ol) {
@@ -342,7 +367,7 @@ CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const flo
 // (valid, finite) weight column and produce values the caller ignores.
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_xt(f4 (&gx)[GE::NGL0][ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
-    constexpr int D = ALG::D, WS = GE::WS;
+    constexpr int D = ALG::D, WS = GE::WS1;
     static_for<0, GE::NGL0>([&](auto t) {
         static_for<0, NOG>([&](auto k) {
             const float* wp = lds + (ge.a_ts[k] + ge.c_t[t]);
@@ -410,16 +435,19 @@ struct RlRed {
     }
     template <int CH>
     CSMPN_DEV void flush() {
+        constexpr int NOG = GE::C / 4;
         float* w = sc + ge.r_w;
         const float* rd = sc + ge.r_r;
         f4 s = ld4(rd);
+        // the 8 source lanes of this lane's (value, channel group): NOG = 2: 8 consecutive lanes;
+        // NOG = 4: 4 rows of each of two DPP rows
 #pragma unroll
-        for (int k = 1; k < 8; ++k) s += ld4(rd + 4 * k);
+        for (int k = 1; k < 8; ++k) s += ld4(rd + 4 * (NOG == 2 ? k : (k & 3) + 16 * (k >> 2)));
         *reinterpret_cast<f4*>(w + 8 * 260) = s;
         const float* r2 = sc + ge.r_r2;
         f4 t = ld4(r2);
 #pragma unroll
-        for (int k = 1; k < 4; ++k) t += ld4(r2 + 64 * k);
+        for (int k = 1; k < 8 / NOG; ++k) t += ld4(r2 + 32 * NOG * k);
         float* a = tot + ge.r_t + CH * 256;
         *reinterpret_cast<f4*>(a) = ld4(a) + t;
     }
@@ -460,13 +488,13 @@ struct RlFwd {
 };
 
 // the part of a block forward after its MVLinear: S.y holds the MVLinear output (without bias).
-// ST = LDS float offset of the block's parameter store.
-template <class ALG, int NOG, int ST, class GE>
+// K = block index (its parameter store: RlLay::o_*(K)).
+template <class ALG, int NOG, int K, class GE>
 CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (&out)[ALG::D]) {
     using LY = typename GE::LY;
     constexpr int D = ALG::D, G = ALG::G, C = 4 * NOG;
     const float* sp = lds + ge.p_og;   // this lane's channel group inside every per-channel array
-    S.y[0] += ld4(sp + (ST + LY::sb1));
+    S.y[0] += ld4(sp + (LY::o_b1(K)));
     // 2. MVSiLU, invariant "mag2" (cegnn_utils.py:76-83)
     f4 z[D];
     static_for<0, G>([&](auto g) {
@@ -481,7 +509,7 @@ CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (
                 u += qsf<ALG, d> * S.y[d] * S.y[d];
             });
         }
-        S.gate[g] = sigmoid4(ld4(sp + (ST + LY::ssa + C * g)) * u + ld4(sp + (ST + LY::ssb + C * g)));
+        S.gate[g] = sigmoid4(ld4(sp + (LY::o_sa(K) + C * g)) * u + ld4(sp + (LY::o_sb(K) + C * g)));
 #pragma unroll
         for (int t = 0; t < nd; ++t) z[d0 + t] = S.gate[g] * S.y[d0 + t];
     });
@@ -491,11 +519,11 @@ CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (
     f4 L[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { S.R[d] = splat(0.f); L[d] = splat(0.f); }
-    rl_linear_d<ALG, NOG, ST + LY::sWR>(S.R, z, lds, ge);
-    rl_linear_d<ALG, NOG, ST + LY::sWL>(L, z, lds, ge);
+    rl_linear_d<ALG, NOG, LY::o_WR(K)>(S.R, z, lds, ge);
+    rl_linear_d<ALG, NOG, LY::o_WL(K)>(L, z, lds, ge);
     ge.stamp(4);
     CSMPN_PHASE();
-    L[0] += ld4(sp + (ST + LY::sbL));
+    L[0] += ld4(sp + (LY::o_bL(K)));
     // 4. NormalizationLayer on the right operand (cegnn_utils.py:42-51)
     f4 r[D];
     static_for<0, G>([&](auto g) {
@@ -505,14 +533,14 @@ CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (
             constexpr int d = d0 + decltype(t)::value;
             qq += qsf<ALG, d> * S.R[d] * S.R[d];
         });
-        const f4 m = ld4(sp + (ST + LY::ssg + C * g)) * (smooth_abs_sqrt4(qq) - 1.0f) + 1.0f;
+        const f4 m = ld4(sp + (LY::o_sg(K) + C * g)) * (smooth_abs_sqrt4(qq) - 1.0f) + 1.0f;
         S.invden[g] = rcp4(m + kEps);
 #pragma unroll
         for (int t = 0; t < nd; ++t) r[d0 + t] = S.R[d0 + t] * S.invden[g];
     });
     ge.stamp(5);
     // 5. steerable geometric product + first-order term (cegnn_utils.py:126-152)
-    rl_weighted_gp<ALG, C>(L, z, r, sp + (ST + LY::sw));
+    rl_weighted_gp<ALG, C>(L, z, r, sp + (LY::o_w(K)));
     ge.stamp(6);
 #pragma unroll
     for (int d = 0; d < D; ++d) S.s[d] = L[d] * kInvSqrt2;
@@ -525,7 +553,7 @@ CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (
     S.qs = qs;
     S.nl = smooth_abs_sqrt4(qs);
     S.invMn = fast_rcp(rl_row_sum<NOG>(hsum(S.nl)) * (1.0f / float(C)) + kEps);
-    const f4 la = ld4(sp + (ST + LY::sla));
+    const f4 la = ld4(sp + (LY::o_la(K)));
 #pragma unroll
     for (int d = 0; d < D; ++d) out[d] = la * S.s[d] * S.invMn;
     ge.stamp(7);
@@ -534,23 +562,27 @@ CSMPN_DEV void rl_block_tail(const float* lds, const GE& ge, RlFwd<ALG>& S, f4 (
 // ---------------------------------------------------------------------------------
 // weight gradients through the per-wave LDS transposition. For every blade d the writers store
 // the slices  A[m][row] (m < 16: gradient channels)  and  B[c][row] (c < NB: input channels) at
-// sc / sc + 16 RS; lane (m = lane & 15, q = lane >> 4) then feeds the 16x16x4 MFMAs with
-// A[m][16t + 4q + v], B[16 nt + m][16t + 4q + v] (one ds_read_b128 each = 4 k-steps; rb[nt] = the
-// lane's clamped B read base). acc[nt][g][v] = sum over the wave's rows of A[4q + v] * B[16 nt + n]
-// for the blades of grade g.
-template <class ALG, int NT, class GE, class WriteA, class WriteB>
-CSMPN_DEV void rl_wgrad(float* sc, const GE& ge, const int (&rb)[NT], f4 (&acc)[NT][ALG::G], WriteA&& write_a, WriteB&& write_b) {
+// sc / sc + b_off; lane (m = lane & 15, q = lane >> 4) then feeds the 16x16x4 MFMAs with
+// A[16 ma + m][16t + 4q + v], B[16 nt + m][16t + 4q + v] (one ds_read_b128 each = 4 k-steps; rb[nt] =
+// the lane's clamped B read base). acc[ma][nt][g][v] = sum over the wave's rows of
+// A[16 ma + 4q + v] * B[16 nt + n] for the blades of grade g.
+template <class ALG, int MA, int NT, class GE, class WriteA, class WriteB>
+CSMPN_DEV void rl_wgrad(float* sc, const GE& ge, const int (&rb)[NT], f4 (&acc)[MA][NT][ALG::G], WriteA&& write_a, WriteB&& write_b) {
+    using LY = typename GE::LY;
     constexpr int D = ALG::D, RS = GE::RS, KT = GE::R / 16;
     static_for<0, D>([&](auto d) {
         constexpr int g = ALG::grade(d);
         write_a(d, sc + ge.s_w);
-        write_b(d, sc + 16 * RS);
+        write_b(d, sc + LY::b_off);
         static_for<0, KT>([&](auto t) {
-            const f4 a = ld4(sc + ge.s_r + 16 * t);
-            static_for<0, NT>([&](auto nt) {
-                const f4 b = ld4(sc + rb[nt] + (16 * RS + 16 * t));
+            f4 b[NT];
+            static_for<0, NT>([&](auto nt) { b[nt] = ld4(sc + rb[nt] + (LY::b_off + 16 * t)); });
+            static_for<0, MA>([&](auto ma) {
+                const f4 a = ld4(sc + ge.s_r + (16 * ma * RS + 16 * t));
+                static_for<0, NT>([&](auto nt) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) acc[nt][g] = mfma16(a[v], b[v], acc[nt][g]);
+                    for (int v = 0; v < 4; ++v) acc[ma][nt][g] = mfma16(a[v], b[nt][v], acc[ma][nt][g]);
+                });
             });
         });
     });
@@ -564,16 +596,15 @@ CSMPN_DEV void rl_wgrad(float* sc, const GE& ge, const int (&rb)[NT], f4 (&acc)[
 // block's input again).
 template <class ALG, int NOG, int K, class GE>
 CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFwd<ALG>& S, const f4 (&gout)[ALG::D],
-                                 f4 (&gy)[ALG::D], float* tot, f4 (&accRL)[1][ALG::G]) {
+                                 f4 (&gy)[ALG::D], float* tot, f4 (&accRL)[GE::LY::MA_RL][1][ALG::G]) {
     using LY = typename GE::LY;
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P, C = 4 * NOG, RS = GE::RS;
-    constexpr int ST = LY::st_off(K);
     using RM = RlRedMap<LY>;
     const float* sp = lds + ge.p_og;
     RlRed<ALG, GE> red(sc, ge, tot);
 
     // ---- MVLayerNorm backward
-    const f4 la = ld4(sp + (ST + LY::sla));
+    const f4 la = ld4(sp + (LY::o_la(K)));
     f4 dot = splat(0.f);
 #pragma unroll
     for (int d = 0; d < D; ++d) dot += gout[d] * S.s[d];
@@ -596,7 +627,7 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
     f4 gz[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) gz[d] = splat(0.f);
-    rl_linear_dt<ALG, NOG, ST + LY::sWL>(gz, ggp, lds, ge);
+    rl_linear_dt<ALG, NOG, LY::o_WL(K)>(gz, ggp, lds, ge);
     ge.stamp(9);
     CSMPN_PHASE();
     // ---- geometric product backward (gz, gr accumulate; d/dw per path reduced at once)
@@ -612,7 +643,7 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
         constexpr int i0 = ALG::gstart(gi), ni = ALG::gsize(gi);
         constexpr int j0 = ALG::gstart(gj), nj = ALG::gsize(gj);
         constexpr int k0 = ALG::gstart(gk), nk = ALG::gsize(gk);
-        const f4 w = ld4(sp + (ST + LY::sw + C * p));
+        const f4 w = ld4(sp + (LY::o_w(K) + C * p));
         // U[i] = sum sign ggp[j] r[k] (unweighted d/dz), V[k] = sum sign ggp[j] z[i] (unweighted d/dr)
         f4 U[ni], V[nk];
 #pragma unroll
@@ -651,7 +682,7 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
         });
         gden *= S.invden[g] * S.invden[g];      // d/d(den): -sum gr * R / den^2
         const f4 nu = smooth_abs_sqrt4(qR);
-        const f4 sg = ld4(sp + (ST + LY::ssg + C * g));
+        const f4 sg = ld4(sp + (LY::o_sg(K) + C * g));
         red.template push<RM::i_an + g>(gden * (nu - 1.0f) * sg * (1.0f - sg));
         const f4 inu = rcp4(nu);
         const f4 gq = (gden * sg) * (0.5f * qR) * (inu * inu * inu);
@@ -662,15 +693,14 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
     });
     ge.stamp(11);
     CSMPN_PHASE();
-    rl_linear_dt<ALG, NOG, ST + LY::sWR>(gz, gR, lds, ge);
+    rl_linear_dt<ALG, NOG, LY::o_WR(K)>(gz, gR, lds, ge);
     ge.stamp(12);
     CSMPN_PHASE();
     // ---- weight gradients of linear_right and linear_left; B = z = gate * y
     {
-        static_assert(NOG == 2, "weight-gradient tiling written for 8 channels");
         const int rb[1] = {ge.s_rbC};
-        // A rows 0..7: gR (-> WR), rows 8..15: ggp (-> WL)
-        rl_wgrad<ALG, 1>(sc, ge, rb, accRL,
+        // A rows 0..C-1: gR (-> WR), rows C..2C-1: ggp (-> WL)
+        rl_wgrad<ALG, LY::MA_RL, 1>(sc, ge, rb, accRL,
             [&](auto d, float* p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { p[i * RS] = gR[d][i]; p[(C + i) * RS] = ggp[d][i]; }
@@ -703,7 +733,7 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
         }
         red.template push<RM::i_sa + 2 * g>(gpre * u);
         red.template push<RM::i_sa + 2 * g + 1>(gpre);
-        const f4 gu = gpre * ld4(sp + (ST + LY::ssa + C * g));
+        const f4 gu = gpre * ld4(sp + (LY::o_sa(K) + C * g));
         static_for<0, nd>([&](auto t) {
             constexpr int d = d0 + decltype(t)::value;
             f4 v = gz[d] * S.gate[g];
@@ -719,15 +749,14 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
 // MVLinear weight gradient of block K: A = gy (the lane's 4 channels), B = the block's input
 // (write_b stores blade d of the input channels into the B slice); acc persists across tiles
 template <class ALG, int NOG, int K, class GE, class WriteB>
-CSMPN_DEV void rl_w1_grad(float* sc, const GE& ge, const f4 (&gy)[ALG::D], f4 (&acc)[(GE::LY::Iof(K) + 15) / 16][ALG::G],
+CSMPN_DEV void rl_w1_grad(float* sc, const GE& ge, const f4 (&gy)[ALG::D], f4 (&acc)[1][(GE::LY::Iof(K) + 15) / 16][ALG::G],
                           WriteB&& write_b) {
-    static_assert(NOG == 2, "weight-gradient tiling written for 8 channels");
     using LY = typename GE::LY;
     constexpr int RS = GE::RS, I = LY::Iof(K), NT = (I + 15) / 16;
     int rb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) rb[nt] = K == 0 ? ge.s_rbX[nt] : ge.s_rbC;
-    rl_wgrad<ALG, NT>(sc, ge, rb, acc,
+    rl_wgrad<ALG, 1, NT>(sc, ge, rb, acc,
         [&](auto d, float* p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) p[i * RS] = gy[d][i];
@@ -739,14 +768,14 @@ CSMPN_DEV void rl_w1_grad(float* sc, const GE& ge, const f4 (&gy)[ALG::D], f4 (&
 // partial buffer (img: >= part_blk(K) floats of the wave's scratch); the caller copies the image out
 // with coalesced 16-byte stores
 template <class ALG, int NOG, int K, class GE>
-CSMPN_DEV void rl_partials_image(float* img, const GE& ge, const f4 (&accW1)[(GE::LY::Iof(K) + 15) / 16][ALG::G],
-                                 const f4 (&accRL)[1][ALG::G], const float* tot) {
+CSMPN_DEV void rl_partials_image(float* img, const GE& ge, const f4 (&accW1)[1][(GE::LY::Iof(K) + 15) / 16][ALG::G],
+                                 const f4 (&accRL)[GE::LY::MA_RL][1][ALG::G], const float* tot) {
     using LY = typename GE::LY;
     using RM = RlRedMap<LY>;
     constexpr int G = ALG::G, C = LY::C, I = LY::Iof(K), NT = (I + 15) / 16;
     const int n = ge.lane & 15, q = ge.lane >> 4;
     // MFMA tile element (i = 4q + v, j = n): W1[o = i][c = 16 nt + n] for i < C
-    if (q < 2) {
+    if (4 * q < C) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int c = 16 * nt + n;
@@ -754,34 +783,31 @@ CSMPN_DEV void rl_partials_image(float* img, const GE& ge, const f4 (&accW1)[(GE
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     float* p = img + ((4 * q + v) * I + c) * G;
-                    if constexpr (G == 4) *reinterpret_cast<f4*>(p) = f4{accW1[nt][0][v], accW1[nt][1][v], accW1[nt][2][v], accW1[nt][3][v]};
-                    else {
 #pragma unroll
-                        for (int g = 0; g < G; ++g) p[g] = accW1[nt][g][v];
-                    }
+                    for (int g = 0; g < G; ++g) p[g] = accW1[0][nt][g][v];
                 }
             }
         }
     }
-    // rows 0..C-1: linear_right, rows C..2C-1: linear_left
+    // A rows 0..C-1: linear_right, rows C..2C-1: linear_left
     if (n < C) {
-        float* base = img + (q < 2 ? LY::pWR(K) : LY::pWL(K)) + ((4 * (q & 1)) * C + n) * G;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            float* p = base + v * C * G;
-            if constexpr (G == 4) *reinterpret_cast<f4*>(p) = f4{accRL[0][0][v], accRL[0][1][v], accRL[0][2][v], accRL[0][3][v]};
-            else {
+        for (int ma = 0; ma < LY::MA_RL; ++ma) {
+            const int i0 = 16 * ma + 4 * q;                       // first of this lane's 4 A rows
+            float* base = img + (i0 < C ? LY::pWR(K) + (i0 * C + n) * G : LY::pWL(K) + ((i0 - C) * C + n) * G);
 #pragma unroll
-                for (int g = 0; g < G; ++g) p[g] = accRL[0][g][v];
-            }
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int g = 0; g < G; ++g) base[v * C * G + g] = accRL[ma][0][g][v];
         }
     }
-    // small parameters: lane L < 16 holds (value L & 7 of every chunk, channel group og)
-    if (ge.lane < 16) {
+    // small parameters: lane L < 8 NOG holds (value L & 7 of every chunk, channel group L >> 3)
+    if (ge.lane < 8 * NOG) {
         float* sm = img + LY::pS(K);
+        const int og_img = ge.lane >> 3;
         static_for<0, LY::n_red>([&](auto idx) {
             if ((ge.lane & 7) == idx % 8) {
-                float* p = sm + RM::off(idx) + 4 * ge.og * RM::stride(idx);
+                float* p = sm + RM::off(idx) + 4 * og_img * RM::stride(idx);
                 const f4 t = ld4(tot + ge.r_t + (idx / 8) * 256);
                 p[0] = t.x; p[RM::stride(idx)] = t.y; p[2 * RM::stride(idx)] = t.z; p[3 * RM::stride(idx)] = t.w;
             }
@@ -906,7 +932,6 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
     using GE = RlGeo<ALG, NOG, NBLK, I0>;
     constexpr int D = ALG::D, C = 4 * NOG, R = GE::R, RS = GE::RS, ROW = C * D, PIECE = 4 * D;
     constexpr int NA = MODE == MODE_EDGE ? I0 - C : (MODE == MODE_NODE ? I0 - 2 * C : 0);   // attribute channels
-    constexpr int ST0 = LY::st_off(0), ST1 = LY::st_off(1);
     static_assert(NBLK == 1 || NBLK == 2, "one or two blocks");
     static_assert(NA >= 0, "bad input width");
     static_assert(LY::bwd_total * 4 <= 160 * 1024, "backward LDS footprint");
@@ -950,22 +975,24 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
     f4 gout_n[ALG::D], in1_n[ALG::D];
     if constexpr (BWD) first_loads(Tn, gout_n, in1_n);
 
-    rl_stage_store<LY, I0>(Cd.b[0], lds + ST0, threadIdx.x);
-    if constexpr (NBLK > 1) rl_stage_store<LY, C>(Cd.b[1], lds + ST1, threadIdx.x);
+    rl_stage_store<LY, 0>(Cd.b[0], lds, threadIdx.x);
+    if constexpr (NBLK > 1) rl_stage_store<LY, 1>(Cd.b[1], lds, threadIdx.x);
     __syncthreads();
     ge.stamp(0);
     // parameter-gradient sums of this wave, persistent across its tiles (backward only)
     constexpr int NT0 = (I0 + 15) / 16, G = ALG::G;
-    f4 accW1_0[NT0][G], accRL_0[1][G];
-    f4 accW1_1[1][G], accRL_1[1][G];
+    f4 accW1_0[1][NT0][G], accRL_0[LY::MA_RL][1][G];
+    f4 accW1_1[1][1][G], accRL_1[LY::MA_RL][1][G];
     float* tot_0 = sc + LY::tot_off;
     float* tot_1 = tot_0 + LY::n_chunk * 256;
     if constexpr (BWD) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
-            for (int nt = 0; nt < NT0; ++nt) accW1_0[nt][g] = splat(0.f);
-            accRL_0[0][g] = splat(0.f); accW1_1[0][g] = splat(0.f); accRL_1[0][g] = splat(0.f);
+            for (int nt = 0; nt < NT0; ++nt) accW1_0[0][nt][g] = splat(0.f);
+            accW1_1[0][0][g] = splat(0.f);
+#pragma unroll
+            for (int ma = 0; ma < LY::MA_RL; ++ma) { accRL_0[ma][0][g] = splat(0.f); accRL_1[ma][0][g] = splat(0.f); }
         }
 #pragma unroll
         for (int c = 0; c < NBLK * LY::n_chunk; ++c) *reinterpret_cast<f4*>(tot_0 + ge.r_t + c * 256) = splat(0.f);
@@ -982,48 +1009,89 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
         const int i_dst = Tc.i_dst, i_src = Tc.i_src, i_perm = Tc.i_perm;
         const float scale = Tc.scale;
         Tn = tile_rows(tile + tstride);
-        // ---- the row's input channels (every lane of the row holds all of them)
-        auto load_input = [&](float (&X)[I0][D]) {
+        // ---- MVLinear of block 0 straight from the gathered rows, 8 input channels at a time (every
+        // lane of a row loads all of them: the NOG lanes issue the same addresses in one instruction)
+        auto mvlinear0 = [&](f4 (&y)[D]) {
+            constexpr int W1 = LY::o_W1(0);
+            auto chunks = [&](auto c0, auto n_total, const float* pa, const float* pb, float mul) {
+                // input channels c0 .. c0 + n_total from the contiguous row at pa (minus the row at pb)
+                static_for<0, (decltype(n_total)::value + 7) / 8>([&](auto q8) {
+                    constexpr int off = 8 * q8, NCH = decltype(n_total)::value - off < 8 ? decltype(n_total)::value - off : 8;
+                    float X[NCH][D];
+                    rl_load_channels<ALG, NCH>(X, 0, pa + off * D);
+                    if (pb) {
+                        float Y[NCH][D];
+                        rl_load_channels<ALG, NCH>(Y, 0, pb + off * D);
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                            for (int d = 0; d < D; ++d) X[c][d] -= Y[c][d];
+                    }
+                    if constexpr (MODE == MODE_NODE) {
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                            for (int d = 0; d < D; ++d) X[c][d] *= mul;
+                    }
+                    rl_linear_x<ALG, W1, decltype(c0)::value + off, NCH>(y, X, lds, ge);
+                });
+            };
             if constexpr (MODE == MODE_EDGE) {
-                float Y[C][D];
-                rl_load_channels<ALG, C>(X, 0, io.seg[0].a + (size_t)i_dst * ROW);
-                rl_load_channels<ALG, C>(Y, 0, io.seg[0].b + (size_t)i_src * ROW);
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-#pragma unroll
-                    for (int d = 0; d < D; ++d) X[c][d] -= Y[c][d];
-                if constexpr (NA > 0) rl_load_channels<ALG, NA>(X, C, io.seg[1].a + (size_t)i_perm * (NA * D));
+                chunks(IC<0>{}, IC<C>{}, io.seg[0].a + (size_t)i_dst * ROW, io.seg[0].b + (size_t)i_src * ROW, 1.0f);
+                if constexpr (NA > 0) chunks(IC<C>{}, IC<NA>{}, io.seg[1].a + (size_t)i_perm * (NA * D), nullptr, 1.0f);
             } else if constexpr (MODE == MODE_NODE) {
-                rl_load_channels<ALG, C>(X, 0, io.seg[0].a + (size_t)lrow * ROW);
-                rl_load_channels<ALG, C>(X, C, io.seg[1].a + (size_t)lrow * ROW);
-#pragma unroll
-                for (int c = C; c < 2 * C; ++c)
-#pragma unroll
-                    for (int d = 0; d < D; ++d) X[c][d] *= scale;
-                if constexpr (NA > 0) rl_load_channels<ALG, NA>(X, 2 * C, io.seg[2].a + (size_t)lrow * (NA * D));
+                chunks(IC<0>{}, IC<C>{}, io.seg[0].a + (size_t)lrow * ROW, nullptr, 1.0f);
+                chunks(IC<C>{}, IC<C>{}, io.seg[1].a + (size_t)lrow * ROW, nullptr, scale);
+                if constexpr (NA > 0) chunks(IC<2 * C>{}, IC<NA>{}, io.seg[2].a + (size_t)lrow * (NA * D), nullptr, 1.0f);
             } else {
-                rl_load_channels<ALG, I0>(X, 0, io.seg[0].a + (size_t)lrow * (I0 * D));
+                chunks(IC<0>{}, IC<I0>{}, io.seg[0].a + (size_t)lrow * (I0 * D), nullptr, 1.0f);
             }
+        };
+        // blade d of the input channels og, og + NOG, ... of this lane's row -> the B slice of the
+        // MVLinear weight gradient (scalar loads of rows the forward has just gathered: cache hits)
+        auto write_input_slice = [&](auto d, float* sB) {
+            float* p = sB + (ge.og * RS + ge.r);
+            static_for<0, (I0 + NOG - 1) / NOG>([&](auto t) {
+                constexpr int cbase = NOG * t;          // segments start at multiples of NOG: one segment per t
+                float v;
+                if constexpr (MODE == MODE_EDGE) {
+                    if constexpr (cbase < C)
+                        v = io.seg[0].a[(size_t)i_dst * ROW + (cbase + ge.og) * D + d] - io.seg[0].b[(size_t)i_src * ROW + (cbase + ge.og) * D + d];
+                    else {
+                        const int ca = cbase - C + ge.og;
+                        v = io.seg[1].a[(size_t)i_perm * (NA * D) + (ca < NA ? ca : NA - 1) * D + d];
+                    }
+                } else if constexpr (MODE == MODE_NODE) {
+                    if constexpr (cbase < C) v = io.seg[0].a[(size_t)lrow * ROW + (cbase + ge.og) * D + d];
+                    else if constexpr (cbase < 2 * C) v = io.seg[1].a[(size_t)lrow * ROW + (cbase - C + ge.og) * D + d] * scale;
+                    else {
+                        const int ca = cbase - 2 * C + ge.og;
+                        v = io.seg[2].a[(size_t)lrow * (NA * D) + (ca < NA ? ca : NA - 1) * D + d];
+                    }
+                } else {
+                    const int ca = cbase + ge.og;
+                    v = io.seg[0].a[(size_t)lrow * (I0 * D) + (ca < I0 ? ca : I0 - 1) * D + d];
+                }
+                if constexpr (cbase + NOG <= I0) p[cbase * RS] = v;
+                else if (cbase + ge.og < I0) p[cbase * RS] = v;
+            });
         };
         // block forward from the gathered input / from a distributed C-channel input
         auto forward0 = [&](RlFwd<ALG>& S, f4 (&out)[D]) {
-            float X[I0][D];
-            load_input(X);
-            ge.stamp(1);
 #pragma unroll
             for (int d = 0; d < D; ++d) S.y[d] = splat(0.f);
-            rl_linear_x<ALG, ST0 + LY::sW1, I0>(S.y, X, lds, ge);
+            mvlinear0(S.y);
             ge.stamp(2);
             CSMPN_PHASE();
-            rl_block_tail<ALG, NOG, ST0>(lds, ge, S, out);
+            rl_block_tail<ALG, NOG, 0>(lds, ge, S, out);
         };
         auto forward1 = [&](const f4 (&in)[D], RlFwd<ALG>& S, f4 (&out)[D]) {
 #pragma unroll
             for (int d = 0; d < D; ++d) S.y[d] = splat(0.f);
-            rl_linear_d<ALG, NOG, ST1 + LY::sW1>(S.y, in, lds, ge);
+            rl_linear_d<ALG, NOG, LY::o_W1(1)>(S.y, in, lds, ge);
             ge.stamp(2);
             CSMPN_PHASE();
-            rl_block_tail<ALG, NOG, ST1>(lds, ge, S, out);
+            rl_block_tail<ALG, NOG, 1>(lds, ge, S, out);
         };
 
         if constexpr (!BWD) {
@@ -1089,7 +1157,7 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 ge.stamp(15);
 #pragma unroll
                 for (int d = 0; d < D; ++d) gout[d] = splat(0.f);
-                rl_linear_dt<ALG, NOG, ST1 + LY::sW1>(gout, gy, lds, ge);
+                rl_linear_dt<ALG, NOG, LY::o_W1(1)>(gout, gy, lds, ge);
                 ge.stamp(16);
                 CSMPN_PHASE();
             }
@@ -1104,31 +1172,13 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                     rl_block_backward<ALG, NOG, 0>(lds, sc, ge, S, gout, gy, tot_0, accRL_0);
                 }
                 CSMPN_PHASE();
-                {
-                    // the block's input again (its registers were released after the MVLinear); lane
-                    // (row, og) writes the input channels og, og + NOG, ... into the B slice
-                    float X[I0][D];
-                    asm volatile("" ::: "memory");   // a fresh gather, not the first one's registers kept alive
-                    load_input(X);
-                    rl_w1_grad<ALG, NOG, 0>(sc, ge, gy, accW1_0, [&](auto d, float* sB) {
-                        float* p = sB + (ge.og * RS + ge.r);
-                        static_for<0, (I0 + NOG - 1) / NOG>([&](auto t) {
-                            constexpr int cbase = NOG * t;
-                            float v = X[cbase][d];
-                            static_for<1, NOG>([&](auto k) {
-                                if constexpr (cbase + k < I0) v = ge.og == k ? X[cbase + k][d] : v;
-                            });
-                            if constexpr (cbase + NOG <= I0) p[cbase * RS] = v;
-                            else if (cbase + ge.og < I0) p[cbase * RS] = v;
-                        });
-                    });
-                }
+                rl_w1_grad<ALG, NOG, 0>(sc, ge, gy, accW1_0, write_input_slice);
                 ge.stamp(15);
 #pragma unroll
                 for (int t = 0; t < NGL; ++t)
 #pragma unroll
                     for (int d = 0; d < D; ++d) gx[t][d] = splat(0.f);
-                rl_linear_xt<ALG, NOG, ST0 + LY::sW1>(gx, gy, lds, ge);
+                rl_linear_xt<ALG, NOG, LY::o_W1(0)>(gx, gy, lds, ge);
                 ge.stamp(16);
             }
             // the next tile's first loads go out in front of this tile's stores / atomics
@@ -1178,20 +1228,24 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
     }
 
     if constexpr (BWD) {
-        static_assert(LY::part_total <= LY::tot_off && LY::part_total % 4 == 0, "slice image must fit below the totals");
-        // every wave builds the image of its sums in its own scratch; the workgroup adds the four
-        // images in wave order and writes ONE slice (coalesced 16-byte stores)
-        rl_partials_image<ALG, NOG, 0>(sc + LY::part_off(0), ge, accW1_0, accRL_0, tot_0);
-        if constexpr (NBLK > 1) rl_partials_image<ALG, NOG, 1>(sc + LY::part_off(1), ge, accW1_1, accRL_1, tot_1);
-        __syncthreads();
+        // block by block: every wave builds the image of its sums in its own scratch; the workgroup adds
+        // the four images in wave order and writes its slice (coalesced 16-byte stores)
         float* part = io.rl_partials + (size_t)blockIdx.x * LY::part_total;
         const float* img = lds + LY::sc_bwd;
-        for (int e = 4 * threadIdx.x; e < LY::part_total; e += 4 * 64 * kRlWaves) {
-            f4 v = ld4(img + e);
+        static_for<0, NBLK>([&](auto kb) {
+            constexpr int n = LY::part_blk(kb);
+            static_assert(n <= LY::tot_off && n % 4 == 0, "slice image must fit below the totals");
+            if constexpr (kb == 0) rl_partials_image<ALG, NOG, 0>(sc, ge, accW1_0, accRL_0, tot_0);
+            else rl_partials_image<ALG, NOG, 1>(sc, ge, accW1_1, accRL_1, tot_1);
+            __syncthreads();
+            for (int e = 4 * threadIdx.x; e < n; e += 4 * 64 * kRlWaves) {
+                f4 v = ld4(img + e);
 #pragma unroll
-            for (int w = 1; w < kRlWaves; ++w) v += ld4(img + w * LY::scratch + e);
-            *reinterpret_cast<f4*>(part + e) = v;
-        }
+                for (int w = 1; w < kRlWaves; ++w) v += ld4(img + w * LY::scratch + e);
+                *reinterpret_cast<f4*>(part + LY::part_off(kb) + e) = v;
+            }
+            __syncthreads();
+        });
     }
 #ifdef CSMPN_STAMPS
     ge.stamp(19);
