@@ -177,6 +177,8 @@ def main():
                     help="N > 1: weak = the workload's edges PER rank; strong = ONE complex sharded over the ranks")
     ap.add_argument("--partition", default="B", choices=["A", "B"],
                     help="N > 1: B = destination-partitioned (all-gather / reduce-scatter), A = edge shards (all-reduce)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="atomic-free aggregation (CSMPN_FLAG_DETERMINISTIC): edge rows to a table + fixed-order segmented sums")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -199,6 +201,8 @@ def main():
 
     pkg = importlib.import_module(PKG)
     from csmpn_hip import ops, sharded
+    if args.deterministic:
+        ops.set_deterministic(True)
 
     metric, C, N, E_per = WORKLOADS[args.workload]
     D = 1 << len(metric)
@@ -366,6 +370,7 @@ def main():
                                    + ", aggr=mean, edge_attr 6ch, node_attr 3ch",
                        "csr_build_ms": None if csr_build_ms is None else round(csr_build_ms, 3),
                        "host_cores": os.cpu_count(),
+                       "aggregation": "deterministic (row table + fixed-order segmented sums)" if args.deterministic else "float atomics",
                        "launch": ("hip-graph replay" if graph is not None else
                                   "hip-graph segments + eager collectives" if segments is not None else "eager"),
                        "sharding": ("none" if world == 1 else

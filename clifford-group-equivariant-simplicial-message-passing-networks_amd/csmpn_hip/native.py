@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("CSMPN_LIB") or os.path.join(_HERE, "libcsmpn_hip.so")
 MAX_BLOCKS = 4
 FLAG_WEIGHTS_PACKED = 1
 FLAG_NO_VALIDATE = 2
+FLAG_DETERMINISTIC = 4
+ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP = 1, 2, 3
 
 # every symbol include/csmpn_hip.h declares
 EXPORTS = (
@@ -29,6 +31,8 @@ EXPORTS = (
     "csmpn_mvlinear_backward",
     "csmpn_csr_workspace_bytes",
     "csmpn_csr_build",
+    "csmpn_csr_source_order",
+    "csmpn_segment_reduce",
     "csmpn_egcl_edge_forward",
     "csmpn_egcl_edge_backward",
     "csmpn_egcl_node_forward",
@@ -87,6 +91,8 @@ def _load():
     sig("csmpn_mvlinear_backward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp])
     sig("csmpn_csr_workspace_bytes", sz, [i64, i64])
     sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_csr_source_order", C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])
+    sig("csmpn_segment_reduce", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, i32, vp])
     sig("csmpn_egcl_edge_forward", C.c_int,
         [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, vp, vp, i64, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_edge_backward", C.c_int,

@@ -7,6 +7,8 @@ There is no eager fallback: CPU tensors or a missing library raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
+import warnings
 from typing import List, Optional, Sequence
 
 import torch
@@ -203,10 +205,71 @@ def cemlp_apply(x, binding: CemlpBinding, params):
 # --------------------------------------------------------------------------------- CSR
 
 
+_DETERMINISTIC = None   # None: follow CSMPN_DETERMINISTIC, else torch.are_deterministic_algorithms_enabled()
+_warned_soft_det = False
+
+
+def set_deterministic(flag):
+    """True / False: force the atomic-free aggregation on / off; None: follow the environment
+    (CSMPN_DETERMINISTIC=0|1) and otherwise torch.use_deterministic_algorithms, which the reference
+    switches on (engineer/utils/seed.py:30)."""
+    global _DETERMINISTIC
+    _DETERMINISTIC = None if flag is None else bool(flag)
+
+
+def deterministic_request():
+    """'hard' (explicitly requested: unsupported shapes raise), 'soft' (inherited from
+    torch.use_deterministic_algorithms: unsupported shapes warn once and use float atomics) or None."""
+    if _DETERMINISTIC is not None:
+        return "hard" if _DETERMINISTIC else None
+    env = os.environ.get("CSMPN_DETERMINISTIC")
+    if env is not None and env != "":
+        return "hard" if env != "0" else None
+    return "soft" if torch.are_deterministic_algorithms_enabled() else None
+
+
+def _soft_fallback(rc):
+    """An unsupported shape under a 'soft' request: warn once, tell the caller to take the atomic path."""
+    global _warned_soft_det
+    if rc != native.ERR_UNSUPPORTED:
+        return False
+    if not _warned_soft_det:
+        _warned_soft_det = True
+        warnings.warn("csmpn_hip: deterministic aggregation is not available for this layer shape "
+                      f"({native.lib().csmpn_last_error().decode()}); using float atomics")
+    return True
+
+
+def segment_reduce(rows, out, add=None, sub=None, accumulate=True):
+    """out[v] (+)= sum rows[add segment of v] - sum rows[sub segment of v] in a fixed order.
+    add / sub: (row_ptr, order or None) int32 device tensors."""
+    ap, ao = add if add is not None else (None, None)
+    sp, so = sub if sub is not None else (None, None)
+    check(native.lib().csmpn_segment_reduce(rows.data_ptr(), rows[0].numel(), out.shape[0], _ptr(ap), _ptr(ao),
+                                            _ptr(sp), _ptr(so), out.data_ptr(), 1 if accumulate else 0,
+                                            _stream(out.device)))
+    return out
+
+
 class Csr:
     """Target-sorted adjacency of one complex (built once, reused by every layer and step)."""
 
-    __slots__ = ("perm", "src", "dst", "deg", "row_ptr", "n_edges", "n_nodes", "build_ms")
+    __slots__ = ("perm", "src", "dst", "deg", "row_ptr", "n_edges", "n_nodes", "build_ms", "_src_order")
+
+    def source_order(self):
+        """(row_ptr_src, order): the sorted edge positions grouped by source (deterministic mode)."""
+        if self._src_order is None:
+            dev = self.src.device
+            order = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+            rp = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+            ws = torch.empty(int(native.lib().csmpn_csr_workspace_bytes(self.n_edges, self.n_nodes)),
+                             dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                check(native.lib().csmpn_csr_source_order(self.src.data_ptr(), self.n_edges, self.n_nodes,
+                                                          order.data_ptr(), rp.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                          _stream(dev)))
+            self._src_order = (rp, order)
+        return self._src_order
 
     def __init__(self, edge_index: torch.Tensor, n_nodes: int):
         if not edge_index.is_cuda:
@@ -218,6 +281,7 @@ class Csr:
         E = ei.shape[1]
         i32 = dict(dtype=torch.int32, device=dev)
         self.n_edges, self.n_nodes = E, n_nodes
+        self._src_order = None
         self.perm = torch.empty(max(E, 1), **i32)
         self.src = torch.empty(max(E, 1), **i32)
         self.dst = torch.empty(max(E, 1), **i32)
@@ -299,6 +363,20 @@ class HipBackend:
         ws = e.workspace(h.device)
         if saved is None and save:
             saved = e.new_saved(csr.n_edges, h.device)
+        det = deterministic_request()
+        if det:
+            if not isinstance(csr, Csr):
+                raise native.CsmpnError("deterministic aggregation needs the whole adjacency (no sliced launches: "
+                                        "set CSMPN_SPLIT_FWD=0)")
+            rows = torch.empty(max(csr.n_edges, 1), spec.O, D, dtype=torch.float32, device=h.device)
+            rc = native.lib().csmpn_egcl_edge_forward(
+                e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
+                csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, rows.data_ptr(),
+                _ptr(saved), ws.data_ptr(), ws.numel(), native.FLAG_DETERMINISTIC, _stream(h.device))
+            if not (det == "soft" and _soft_fallback(rc)):
+                check(rc)
+                segment_reduce(rows, agg, add=(csr.row_ptr, None))
+                return agg, (ws, saved)
         check(native.lib().csmpn_egcl_edge_forward(
             e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
             csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, agg.data_ptr(),
@@ -351,6 +429,20 @@ class HipBackend:
         g_ea = torch.empty_like(edge_attr) if (edge_attr is not None and want_gea) else None
         ws, saved = state if state is not None else (e.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
+        det = deterministic_request()
+        if det:
+            if not isinstance(csr, Csr):
+                raise native.CsmpnError("deterministic aggregation needs the whole adjacency (no sliced launches)")
+            rows = torch.empty(max(csr.n_edges, 1), spec.C, e.D, dtype=torch.float32, device=dev)
+            rc = native.lib().csmpn_egcl_edge_backward(
+                e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
+                csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(),
+                rows.data_ptr(), _ptr(g_ea), _ptr(saved), ws.data_ptr(), ws.numel(),
+                flags | native.FLAG_DETERMINISTIC, _stream(dev))
+            if not (det == "soft" and _soft_fallback(rc)):
+                check(rc)
+                segment_reduce(rows, gh, add=(csr.row_ptr, None), sub=csr.source_order())
+                return g_ea, views
         check(native.lib().csmpn_egcl_edge_backward(
             e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
             csr.perm.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr(), csr.n_edges, N, g_agg.data_ptr(),

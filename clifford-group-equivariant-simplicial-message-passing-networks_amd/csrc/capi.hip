@@ -552,6 +552,10 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (handled) return CSMPN_OK;
         }
     }
+    if (io.row_store)
+        return fail(CSMPN_ERR_UNSUPPORTED,
+                    "CSMPN_FLAG_DETERMINISTIC needs the row-per-lane kernels (Cl(3,0), 8 or 16 channels, <= 2 blocks, "
+                    "saved block inputs): the other kernel families sum parameter gradients with float atomics");
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
     // few tiles (e.g. the node update of a 10k-node complex): fewer row tiles per workgroup,
@@ -876,6 +880,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     io.seg[0].a = h; io.seg[0].ia = dst_sorted; io.seg[0].b = h; io.seg[0].ib = src_sorted; io.seg[0].ch = channels;
     io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
     io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm; io.save = save_inputs;
+    io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // agg is then the [E, O, D] message table
     (void)N;
     return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream);
 }
@@ -896,7 +901,6 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     if (rc) return rc;
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
-    (void)flags;
     if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
     RowIO io;
     memset(&io, 0, sizeof(io));
@@ -905,6 +909,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
     io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
     io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr; io.saved = saved_inputs;
+    io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // gh is then the [E, C, D] per-edge gradient table
     (void)N;
     return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream);
 }

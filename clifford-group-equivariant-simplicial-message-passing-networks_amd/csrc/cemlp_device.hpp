@@ -116,6 +116,11 @@ struct RowIO {
     const float* saved;
     unsigned long long* stamps;   // diagnostic (-DCSMPN_STAMPS) cycle accumulators, else null
     float* rl_partials;     // row-per-lane backward (cemlp_rl.hpp): one slice of parameter-gradient sums per workgroup
+    // deterministic mode (CSMPN_FLAG_DETERMINISTIC, row-per-lane kernels only): EDGE rows are not
+    // scattered; `agg` (forward) / `gx[0]` (backward) is an [rows, C, D] table in sorted edge order
+    // that a segmented reduction sums afterwards in a fixed order
+    int row_store;
+    int pad3_;
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

@@ -1110,8 +1110,12 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 forward1(in1, S, out);
             }
             if constexpr (MODE == MODE_EDGE) {
-                rl_store_t<ALG>(out, sc + ge.g_st, 1.0f);
-                rl_scatter<GE, ROW, false>(sc, valid ? i_dst : -1, -1, io.agg, ge.lane);
+                if (io.row_store) {
+                    if (valid) rl_store_t<ALG>(out, io.agg + (size_t)lrow * ROW + ge.og * PIECE, 1.0f);
+                } else {
+                    rl_store_t<ALG>(out, sc + ge.g_st, 1.0f);
+                    rl_scatter<GE, ROW, false>(sc, valid ? i_dst : -1, -1, io.agg, ge.lane);
+                }
                 ge.stamp(18);
             } else {
                 if (valid) {
@@ -1186,8 +1190,12 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
             // gx[t] = d/d(input channels 4(og + NOG t) .. +3)
             if constexpr (MODE == MODE_EDGE) {
                 if (io.gx[0]) {
-                    rl_store_t<ALG>(gx[0], sc + ge.g_st, 1.0f);
-                    rl_scatter<GE, ROW, true>(sc, valid ? i_dst : -1, valid ? i_src : -1, io.gx[0], ge.lane);
+                    if (io.row_store) {
+                        if (valid) rl_store_t<ALG>(gx[0], io.gx[0] + (size_t)lrow * ROW + ge.og * PIECE, 1.0f);
+                    } else {
+                        rl_store_t<ALG>(gx[0], sc + ge.g_st, 1.0f);
+                        rl_scatter<GE, ROW, true>(sc, valid ? i_dst : -1, valid ? i_src : -1, io.gx[0], ge.lane);
+                    }
                 }
                 if constexpr (NA > 0) {
                     if (io.gx[1] && valid) {

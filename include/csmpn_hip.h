@@ -55,6 +55,14 @@ extern "C" {
                                        ignored by the backward entry points, which pack for their own
                                        tile layout when it needs packed fragments at all. */
 
+#define CSMPN_FLAG_DETERMINISTIC 4u  /* csmpn_egcl_edge_forward/backward: no float atomics. The edge rows are
+                                       not scattered: `agg` (forward) / `gh` (backward) is an [E, C, D] table in
+                                       SORTED edge order, to be summed by csmpn_segment_reduce in a fixed order
+                                       (the reference runs under torch.use_deterministic_algorithms(True),
+                                       engineer/utils/seed.py:30). Only the kernels whose parameter-gradient
+                                       sums are atomic-free honour it (Cl(3,0), 8 or 16 channels, <= 2 blocks,
+                                       saved block inputs); every other shape returns CSMPN_ERR_UNSUPPORTED. */
+
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
 typedef struct csmpn_block_params {
@@ -156,6 +164,22 @@ size_t csmpn_csr_workspace_bytes(int64_t n_edges, int64_t n_nodes);
 int csmpn_csr_build(const int64_t* edge_index, int64_t n_edges, int64_t n_nodes, int32_t* perm,
                     int32_t* src_sorted, int32_t* dst_sorted, int32_t* in_degree, int32_t* row_ptr,
                     void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
+/* Deterministic mode, one-time per complex: the sorted edge positions ordered by SOURCE (stable, so
+ * ascending sorted position inside one source's segment). order[E], row_ptr_src[N+1] (device, int32);
+ * workspace as for csmpn_csr_build. */
+int csmpn_csr_source_order(const int32_t* src_sorted, int64_t n_edges, int64_t n_nodes, int32_t* order,
+                           int32_t* row_ptr_src, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Fixed-order segmented sum of a row table (the replacement of PyG's scatter under
+ * deterministic algorithms):
+ *   out[v] (+)= sum_{k in [add_ptr[v], add_ptr[v+1])} rows[add_order ? add_order[k] : k]
+ *             - sum_{k in [sub_ptr[v], sub_ptr[v+1])} rows[sub_order ? sub_order[k] : k]
+ * rows [*, row_floats], out [N, row_floats] (16-byte aligned, row_floats % 4 == 0); either
+ * (ptr, order) pair may be NULL; accumulate != 0 adds to out instead of overwriting it. */
+int csmpn_segment_reduce(const float* rows, int64_t row_floats, int64_t n_nodes, const int32_t* add_ptr,
+                         const int32_t* add_order, const int32_t* sub_ptr, const int32_t* sub_order, float* out,
+                         int32_t accumulate, void* stream);
 
 /* EGCL message + aggregate (cegnn_utils.py:254-262 + PyG scatter):
  *   agg[v] += sum_{e: dst_e = v} EdgeCEMLP(cat_c[h[dst_e] - h[src_e], edge_attr[perm_e]])
