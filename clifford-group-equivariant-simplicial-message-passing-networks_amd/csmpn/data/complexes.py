@@ -168,6 +168,32 @@ class SimplicialBatch:
     def num_graphs(self) -> int:
         return int(self.ptr.shape[0]) - 1
 
+    def plan(self, max_dim: int = 2):
+        """Index tables of the embedding stage, computed once per batch (the only host round trips of
+        a model step: everything downstream uses fixed-shape index_select / index_copy and can be
+        captured in a HIP graph):
+          rows[d]   rows of the d-simplices                                    [n_d]
+          verts[d]  their vertices in all (d+1)! orders, as batch rows          [n_d * (d+1)!, d+1]
+          vertex_rows = rows[0]; graph_of_vertex = graph id of every vertex row."""
+        cached = getattr(self, "_plan", None)
+        if cached is not None and cached["max_dim"] == max_dim:
+            return cached
+        import itertools
+        start = self.x_ind_ptr[:-1][self.x_ind_batch]
+        vrows = self.x_ind.long() + start.unsqueeze(-1)
+        plan = {"max_dim": max_dim, "rows": [], "verts": [], "nperm": []}
+        for d in range(max_dim + 1):
+            rows = torch.nonzero(self.node_types == d, as_tuple=False).flatten()
+            perms = torch.tensor(list(itertools.permutations(range(d + 1))), device=rows.device)
+            plan["rows"].append(rows)
+            plan["verts"].append(vrows[rows][:, : d + 1][:, perms].reshape(-1, d + 1).contiguous())
+            plan["nperm"].append(int(perms.shape[0]))
+        plan["vertex_rows"] = plan["rows"][0]
+        plan["graph_of_vertex"] = self.batch[plan["rows"][0]]
+        plan["vertices_per_graph"] = torch.bincount(plan["graph_of_vertex"], minlength=self.num_graphs)
+        self._plan = plan
+        return plan
+
     def csr(self):
         """Target-sorted adjacency of the batch, built once (device batches only)."""
         if self._csr is None:

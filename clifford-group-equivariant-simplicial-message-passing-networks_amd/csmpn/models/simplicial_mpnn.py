@@ -59,26 +59,31 @@ class SimplexEmbedding(nn.Module):
 
     def forward(self, batch, vertex_blocks: Sequence[Tuple[torch.Tensor, int]]) -> torch.Tensor:
         """vertex_blocks: [(tensor [S, K, n_g], grade g)]: K channels per vertex, embedded as grade g.
-        Channel order of a d-simplex row: block by block, inside a block vertex by vertex."""
-        rows = simplex_vertex_rows(batch)
-        D = 2 ** self.algebra.dim
-        out = torch.zeros(batch.x_ind.shape[0], self.hidden_features, D, device=batch.x_ind.device)
+        Channel order of a d-simplex row: block by block, inside a block vertex by vertex.
+        The index tables come from batch.plan() (computed once per batch): no data-dependent shapes
+        here, so a whole model step can be captured in a HIP graph."""
+        plan = batch.plan(self.max_dim)
+        n = self.algebra.dim
+        D = 2 ** n
+        dev = batch.x_ind.device
+        out = torch.zeros(batch.x_ind.shape[0], self.hidden_features, D, device=dev)
+        fused = dev.type == "cuda" and not any(t.requires_grad for t, _ in vertex_blocks)
         for d in range(self.max_dim + 1):
-            sel = batch.node_types == d
-            verts = rows[sel, : d + 1]                      # [n_d, d+1]
-            if verts.shape[0] == 0:
+            rows, pv, nperm = plan["rows"][d], plan["verts"][d], plan["nperm"][d]
+            if rows.shape[0] == 0:
                 continue
-            perms = torch.tensor(list(itertools.permutations(range(d + 1))), device=verts.device)
-            nperm = math.factorial(d + 1)
-            pv = verts[:, perms].reshape(-1, d + 1)         # [n_d * (d+1)!, d+1]
-            feats = []
-            for t, grade in vertex_blocks:
-                g = t[pv]                                   # [rows, d+1, K, n_g]
-                g = g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2])
-                feats.append(self.algebra.embed_grade(g, grade))
-            x = feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)
-            e = self.cl_feature_embedding[d](x.contiguous())
-            out[sel] = e.reshape(verts.shape[0], nperm, self.hidden_features, D).sum(dim=1)
+            if fused:
+                from csmpn_hip import ops
+                x = ops.simplex_rows(n, [(t, g) for t, g in vertex_blocks], pv)   # one gather + embed kernel
+            else:
+                feats = []
+                for t, grade in vertex_blocks:
+                    g = t[pv]                                   # [rows, d+1, K, n_g]
+                    g = g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2])
+                    feats.append(self.algebra.embed_grade(g, grade))
+                x = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)).contiguous()
+            e = self.cl_feature_embedding[d](x)
+            out = out.index_copy(0, rows, e.reshape(rows.shape[0], nperm, self.hidden_features, D).sum(dim=1))
         return out
 
 
@@ -112,20 +117,28 @@ class HullsSimplicialMPNN(nn.Module):
         B = batch.num_graphs
         n = self.algebra.dim
         inp = batch.input
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
         # centre the vertices of every graph (hulls_cssmpnn.py:145-148)
-        is_v = batch.node_types == 0
-        pos = inp[is_v].reshape(B, -1, n)
+        pos = inp.index_select(0, vr).reshape(B, -1, n)
         centred = (pos - pos.mean(dim=1, keepdim=True)).reshape(-1, n)
-        inp = inp.clone()
-        inp[is_v] = centred
+        inp = inp.index_copy(0, vr, centred)
         x = self._embed(batch, [(inp.unsqueeze(1), 1)])
         types = torch.nn.functional.one_hot(batch.node_types, self.num_node_type).float()
         node_attr, edge_attr = type_attributes(self.algebra, types, batch.edge_index)
         for layer in self.layers:
             x = layer(x, batch.edge_index, node_attr=node_attr, edge_attr=edge_attr)
-        pred = self.projection(x)[:, :, 0]
-        pred = segment_mean(pred, batch.x_ind_batch, B)
-        loss = (pred.squeeze(-1) - batch.target) ** 2
+        head = self.projection[0]
+        if x.is_cuda and len(self.projection) == 1 and head.out_features == 1 and head.weight.dim() == 3:
+            # fused readout + loss (csmpn_readout_mse_*): blade 0 of the projection, mean per graph, squared error
+            from csmpn_hip import ops
+            if "ptr_i32" not in plan:
+                plan["ptr_i32"] = batch.x_ind_ptr.to(torch.int32)
+            loss, _pred = ops.readout_mse(x, head.weight, getattr(head, "bias", None), plan["ptr_i32"], batch.target, n)
+        else:
+            pred = self.projection(x)[:, :, 0]
+            pred = segment_mean(pred, batch.x_ind_batch, B)
+            loss = (pred.squeeze(-1) - batch.target) ** 2
         return loss.mean(0), {"loss": loss}
 
 
@@ -152,10 +165,11 @@ class MD17SimplicialMPNN(nn.Module):
     def forward(self, batch, step=0, mode="train"):
         B = batch.num_graphs
         F_ = batch.loc.shape[1]                       # frames
-        is_v = batch.node_types == 0
-        loc_node = batch.loc[is_v]
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        loc_node = batch.loc.index_select(0, vr)
         # mean position of a graph's vertices over vertices and frames (md17_cssmpnn.py:135-139)
-        per_graph = segment_mean(loc_node.reshape(-1, F_ * 3), batch.batch[is_v], B).reshape(B, F_, 3)
+        per_graph = segment_mean(loc_node.reshape(-1, F_ * 3), plan["graph_of_vertex"], B).reshape(B, F_, 3)
         per_graph = per_graph.mean(dim=1, keepdim=True).expand(B, F_, 3)
         pos = batch.loc - per_graph[batch.x_ind_batch]
         node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
@@ -163,7 +177,7 @@ class MD17SimplicialMPNN(nn.Module):
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
-        pred = self.projection(x[is_v].contiguous())[..., 1:4]
+        pred = self.projection(x.index_select(0, vr))[..., 1:4]
         loc_pred = loc_node + pred
         tgt = batch.y
         sq = ((loc_pred.reshape(-1, 3) - tgt.reshape(-1, 3)) ** 2)

@@ -1,0 +1,89 @@
+"""Whole-model training step replayed from ONE HIP graph (multi-layer step).
+
+A step of the reference's trainer (engineer/trainer/trainer.py:204-227) is
+    optimizer.zero_grad(); loss, _ = model(batch); loss.backward(); optimizer.step()
+i.e. for the hulls model ~3 x 4 fused CEMLP launches between ~150 small PyTorch launches (embedding
+gathers, attribute concatenation, pooling, Adam). On complexes of the reference's sizes (a few thousand
+simplices per batch) the GPU work of a step is shorter than the host time to launch it, so the step is
+launch-bound. For batches of FIXED topology (same complexes, new vertex features / targets: MD17
+trajectories of one molecule, repeated epochs over cached batches) this module captures the whole step -
+embedding, every EGCL layer forward and backward, readout, loss and the optimizer update - once and replays
+it; per step the host copies the new features into the captured buffers and launches one graph.
+
+The kernels launched inside are the same C-ABI calls as in eager mode (they take the current stream); the
+CSR and the embedding index tables are built before capture (their only host round trips).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+
+class GraphedTrainStep:
+    """step(features) -> loss (a device scalar that the next replay overwrites).
+
+    model(batch) must return (loss, aux) like the reference's task models; `optimizer` must be
+    graph-capturable (torch.optim.Adam(..., capturable=True)); `batch` is a device SimplicialBatch
+    whose tensors become the captured input buffers. `feature_names`: the batch attributes that change
+    from step to step (everything else - topology, types - is part of the captured graph)."""
+
+    def __init__(self, model, optimizer, batch, feature_names: Iterable[str], warmup: int = 2, max_dim: Optional[int] = None):
+        dev = batch.edge_index.device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs a device batch (no CPU fallback)")
+        self.model, self.optimizer, self.batch = model, optimizer, batch
+        self.feature_names = list(feature_names)
+        for name in self.feature_names:
+            if not hasattr(batch, name):
+                raise AttributeError(f"batch has no feature {name!r}")
+        batch.plan(getattr(model, "max_dim", 2) if max_dim is None else max_dim)
+        batch.csr()
+        # warm-up steps run eagerly on a side stream (allocator pools, lazily built workspaces, Adam state
+        # tensors); parameters and optimizer state are restored afterwards, so the first replayed step is
+        # step 1 of the trajectory
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        saved_params = [p.detach().clone() for p in params]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                self._eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for p, s in zip(params, saved_params):
+                p.copy_(s)
+            # optimizer state (exp_avg, exp_avg_sq, step) exists now: reset it in place, the captured
+            # graph updates these very tensors
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.aux = self._eager_step()
+        # the capture itself executes nothing: parameters and optimizer state are still those of step 0
+
+    def _eager_step(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        loss, aux = self.model(self.batch)
+        loss.backward()
+        self.optimizer.step()
+        return loss, aux
+
+    def load(self, features: Dict[str, torch.Tensor]):
+        """Copy new feature tensors (same shapes) into the captured buffers."""
+        for name, value in features.items():
+            if name not in self.feature_names:
+                raise KeyError(f"{name!r} was not declared as a changing feature")
+            getattr(self.batch, name).copy_(value, non_blocking=True)
+
+    def step(self, features: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        if features:
+            self.load(features)
+        self.graph.replay()
+        return self.loss

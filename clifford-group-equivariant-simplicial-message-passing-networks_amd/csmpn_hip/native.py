@@ -37,6 +37,9 @@ EXPORTS = (
     "csmpn_egcl_edge_backward",
     "csmpn_egcl_node_forward",
     "csmpn_egcl_node_backward",
+    "csmpn_simplex_rows",
+    "csmpn_readout_mse_forward",
+    "csmpn_readout_mse_backward",
     "csmpn_last_error",
     "csmpn_abi_version",
     "csmpn_build_target",
@@ -56,6 +59,10 @@ class BlockParams(C.Structure):
 
 class BlockGrads(C.Structure):
     _fields_ = [(name, C.c_void_p) for name in PARAM_FIELDS]
+
+
+class VertexBlock(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("channels", C.c_int32), ("grade", C.c_int32)]
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -101,6 +108,9 @@ def _load():
         [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_egcl_node_backward", C.c_int,
         [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_simplex_rows", C.c_int, [C.c_int, C.POINTER(VertexBlock), C.c_int, vp, i64, i32, i64, vp, vp])
+    sig("csmpn_readout_mse_forward", C.c_int, [C.c_int, vp, vp, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp])
+    sig("csmpn_readout_mse_backward", C.c_int, [C.c_int, vp, i32, i64, i32, vp, i64, vp, vp, vp])
     sig("csmpn_last_error", C.c_char_p, [])
     sig("csmpn_abi_version", C.c_int, [])
     sig("csmpn_build_target", C.c_char_p, [])

@@ -614,3 +614,107 @@ def mvlinear_apply(x, weight, bias, n):
 
 def geometric_product_apply(a, b, metric):
     return _GpFn.apply(a, b, tuple(float(m) for m in metric))
+
+
+# --------------------------------------------------------------------------------- callers either side (SURVEY §8(f)-1,2)
+
+
+@_on_device_of(1)
+def simplex_rows(n: int, blocks, verts: torch.Tensor) -> torch.Tensor:
+    """Input rows of the simplex feature embedding (csmpn_simplex_rows). blocks: [(tensor [S, K, n_g], grade)],
+    verts [rows, d+1] int64 batch rows of the vertices in one vertex order. The feature tensors are data
+    (no gradient flows to them in the reference's models): tensors that require grad are refused."""
+    if not verts.is_cuda:
+        raise RuntimeError("simplex vertex table must live on the GPU (no CPU fallback)")
+    if verts.dtype != torch.int64 or verts.dim() != 2:
+        raise RuntimeError("verts must be int64 [rows, vertices]")
+    verts = verts.contiguous()
+    arr = (native.VertexBlock * len(blocks))()
+    keep, ctot, S = [], 0, None
+    for i, (t, grade) in enumerate(blocks):
+        if t.requires_grad:
+            raise RuntimeError("simplex_rows: feature tensors are inputs (no gradient); detach them")
+        _require_device(t, "simplex feature block")
+        t = t.contiguous()
+        if t.dim() != 3 or t.dtype != torch.float32 or t.device != verts.device:
+            raise RuntimeError(f"feature block {i} must be float32 [S, K, n_g] on {verts.device}")
+        if t.shape[2] != _binom(n, int(grade)):
+            raise RuntimeError(f"feature block {i}: last dimension {t.shape[2]} is not the size of grade {grade}")
+        if S is None:
+            S = t.shape[0]
+        elif S != t.shape[0]:
+            raise RuntimeError("feature blocks disagree on the number of rows")
+        keep.append(t)
+        arr[i].data, arr[i].channels, arr[i].grade = t.data_ptr(), t.shape[1], int(grade)
+        ctot += verts.shape[1] * t.shape[1]
+    out = torch.empty(verts.shape[0], ctot, 1 << n, dtype=torch.float32, device=verts.device)
+    check(native.lib().csmpn_simplex_rows(n, arr, len(blocks), verts.data_ptr(), verts.shape[0], verts.shape[1], S,
+                                          out.data_ptr(), _stream(verts.device)))
+    return out
+
+
+def _binom(n, k):
+    import math
+    return math.comb(n, k)
+
+
+class _ReadoutMseFn(torch.autograd.Function):
+    """loss_g = (mean_{s in g} MVLinear(x)[s, 0, blade 0] - target_g)^2 (hulls_cssmpnn.py:93,155-164)."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, x, weight, bias, graph_ptr, target, n):
+        _require_device(x, "readout input")
+        x = x.contiguous()
+        S, Cc, D = x.shape
+        if weight.shape[0] != 1 or weight.shape[1] != Cc or D != (1 << n):
+            raise RuntimeError(f"readout: weight {tuple(weight.shape)} does not fit input {tuple(x.shape)} with out_features = 1")
+        w = weight.contiguous()
+        stride = w.shape[2] if w.dim() == 3 else 1
+        b = bias.contiguous() if bias is not None else None
+        B = graph_ptr.shape[0] - 1
+        tgt = target.contiguous().float()
+        pred = torch.empty(B, dtype=torch.float32, device=x.device)
+        loss = torch.empty(B, dtype=torch.float32, device=x.device)
+        xs = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        check(native.lib().csmpn_readout_mse_forward(n, x.data_ptr(), w.data_ptr(), stride, _ptr(b), S, Cc,
+                                                     graph_ptr.data_ptr(), B, tgt.data_ptr(), pred.data_ptr(),
+                                                     loss.data_ptr(), xs.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(w, graph_ptr, pred, tgt, xs)
+        ctx.n, ctx.shape, ctx.has_bias = n, (S, Cc, D), bias is not None
+        ctx.mark_non_differentiable(pred)
+        return loss, pred
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, g_loss, _g_pred):
+        w, graph_ptr, pred, tgt, xs = ctx.saved_tensors
+        S, Cc, D = ctx.shape
+        B = graph_ptr.shape[0] - 1
+        cnt = (graph_ptr[1:] - graph_ptr[:-1]).clamp(min=1).float()
+        dpred = g_loss.contiguous() * 2.0 * (pred - tgt)            # d/d pred_g
+        coef = (dpred / cnt).contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(S, Cc, D, dtype=torch.float32, device=w.device)
+            stride = w.shape[2] if w.dim() == 3 else 1
+            check(native.lib().csmpn_readout_mse_backward(ctx.n, w.data_ptr(), stride, S, Cc, graph_ptr.data_ptr(), B,
+                                                          coef.data_ptr(), gx.data_ptr(), _stream(w.device)))
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.zeros_like(w)
+            gc = coef @ xs                                           # [C]
+            if w.dim() == 3:
+                gw[0, :, 0] = gc
+            else:
+                gw[0, :] = gc
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            nonempty = ((graph_ptr[1:] - graph_ptr[:-1]) > 0).float()
+            gb = (dpred * nonempty).sum().reshape(1, 1, 1)
+        return gx, gw, gb, None, None, None
+
+
+def readout_mse(x, weight, bias, graph_ptr_i32, target, n):
+    """(loss per graph, prediction per graph); graph_ptr_i32 [B+1] int32 device tensor (rows of a graph are contiguous)."""
+    return _ReadoutMseFn.apply(x, weight, bias, graph_ptr_i32, target, int(n))

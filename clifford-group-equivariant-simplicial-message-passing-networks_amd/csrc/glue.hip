@@ -1,0 +1,183 @@
+// Callers either side of the message-passing path (SURVEY.md §8(f)-1,2), C-ABI in include/csmpn_hip.h:
+//   csmpn_simplex_rows          input rows of the simplex feature embedding: gather the vertices of every
+//                               simplex in a given vertex order and embed their features at a grade
+//                               (hulls_cssmpnn.py:96-125, md17_cssmpnn.py:85-120)
+//   csmpn_readout_mse_forward / _backward
+//                               scalar readout + loss of the hulls model: MVLinear -> blade 0 -> mean over
+//                               the simplices of a graph -> squared error (hulls_cssmpnn.py:93,155-164)
+// HBM-bound gathers / reductions: one pass over the data, coalesced rows, fixed-order sums (no atomics).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/csmpn_hip.h"
+#include "capi_common.hpp"
+
+namespace {
+
+constexpr int kMaxVertexBlocks = 4;
+
+struct RowsDesc {
+    const float* data[kMaxVertexBlocks];
+    int channels[kMaxVertexBlocks];   // K_b
+    int gstart[kMaxVertexBlocks];     // first blade of the grade
+    int gsize[kMaxVertexBlocks];      // blades of the grade
+    int choff[kMaxVertexBlocks + 1];  // first output channel of the block
+    int nblocks;
+    int vpr;                          // vertices per row
+    int D;
+};
+
+// one thread per output element: out[r][ch][d]
+__global__ void simplex_rows_kernel(RowsDesc ds, const int64_t* verts, long n_rows, long n_feat_rows, float* out) {
+    const int ctot = ds.choff[ds.nblocks];
+    const long rowlen = (long)ctot * ds.D;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * rowlen) return;
+    const long r = t / rowlen;
+    const int e = (int)(t - r * rowlen);
+    const int ch = e / ds.D, d = e - ch * ds.D;
+    float v = 0.f;
+#pragma unroll
+    for (int b = 0; b < kMaxVertexBlocks; ++b) {
+        if (b < ds.nblocks && ch >= ds.choff[b] && ch < ds.choff[b + 1]) {
+            const int lc = ch - ds.choff[b];
+            const int vert = lc / ds.channels[b], k = lc - vert * ds.channels[b];
+            const int td = d - ds.gstart[b];
+            if (td >= 0 && td < ds.gsize[b]) {
+                long src = verts[r * ds.vpr + vert];
+                if (src < 0 || src >= n_feat_rows) src = 0;   // validated on the host side of the binding
+                v = ds.data[b][(src * ds.channels[b] + k) * ds.gsize[b] + td];
+            }
+        }
+    }
+    out[t] = v;
+}
+
+// one workgroup per graph: pred = mean_s (sum_c w[c] x[s][c][0] + b), loss = (pred - target)^2,
+// xsum[g][c] = sum_s x[s][c][0] (for the weight gradient). Fixed-order tree sums.
+__global__ void __launch_bounds__(256) readout_fwd_kernel(const float* x, const float* w, int wstride, const float* bias, int C,
+                                                          int D, const int* ptr, const float* target, float* pred,
+                                                          float* loss, float* xsum) {
+    __shared__ float red[256];
+    const int g = blockIdx.x;
+    const int lo = ptr[g], hi = ptr[g + 1];
+    const int cnt = hi - lo;
+    float total = 0.f;
+    for (int c = 0; c < C; ++c) {
+        float a = 0.f;
+        for (int s = lo + threadIdx.x; s < hi; s += 256) a += x[((long)s * C + c) * D];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+            __syncthreads();
+        }
+        const float sc = red[0];
+        __syncthreads();
+        if (threadIdx.x == 0) xsum[(long)g * C + c] = sc;
+        total += w[(long)c * wstride] * sc;
+    }
+    if (threadIdx.x == 0) {
+        const float n = float(cnt > 1 ? cnt : 1);
+        const float p = total / n + (cnt > 0 && bias ? bias[0] : 0.f);
+        pred[g] = p;
+        const float e = p - target[g];
+        loss[g] = e * e;
+    }
+}
+
+// gx[s][c][d] = (d == 0) ? coef[graph(s)] * w[c] : 0, coef_g = g_loss_g * 2 (pred_g - target_g) / max(cnt_g, 1)
+__global__ void readout_bwd_kernel(const float* w, int wstride, int C, int D, const int* ptr, int B, const float* coef,
+                                   long S, float* gx) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)C * D;
+    if (t >= S * per) return;
+    const long s = t / per;
+    const int e = (int)(t - s * per);
+    const int c = e / D, d = e - c * D;
+    float v = 0.f;
+    if (d == 0) {
+        int lo = 0, hi = B;   // graph of row s: last g with ptr[g] <= s
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (ptr[mid] <= s) lo = mid; else hi = mid;
+        }
+        v = coef[lo] * w[(long)c * wstride];
+    }
+    gx[t] = v;
+}
+
+int grade_start(int n, int g) {
+    int s = 0, c = 1;
+    for (int i = 0; i < g; ++i) { s += c; c = c * (n - i) / (i + 1); }
+    return s;
+}
+int grade_size(int n, int g) {
+    int c = 1;
+    for (int i = 0; i < g; ++i) c = c * (n - i) / (i + 1);
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int csmpn_simplex_rows(int n, const csmpn_vertex_block* blocks, int n_blocks, const int64_t* verts, int64_t n_rows,
+                       int32_t verts_per_row, int64_t n_feature_rows, float* out, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_blocks < 1 || n_blocks > kMaxVertexBlocks) return csmpn_fail(CSMPN_ERR_INVALID, "1..%d vertex blocks", kMaxVertexBlocks);
+    if (n_rows <= 0) return CSMPN_OK;
+    if (!blocks || !verts || !out || verts_per_row < 1 || n_feature_rows < 1) return csmpn_fail(CSMPN_ERR_INVALID, "bad arguments");
+    RowsDesc ds{};
+    ds.nblocks = n_blocks; ds.vpr = verts_per_row; ds.D = 1 << n;
+    ds.choff[0] = 0;
+    for (int b = 0; b < n_blocks; ++b) {
+        if (!blocks[b].data || blocks[b].channels < 1 || blocks[b].grade < 0 || blocks[b].grade > n)
+            return csmpn_fail(CSMPN_ERR_INVALID, "vertex block %d: bad data / channels / grade", b);
+        ds.data[b] = blocks[b].data;
+        ds.channels[b] = blocks[b].channels;
+        ds.gstart[b] = grade_start(n, blocks[b].grade);
+        ds.gsize[b] = grade_size(n, blocks[b].grade);
+        ds.choff[b + 1] = ds.choff[b] + verts_per_row * blocks[b].channels;
+    }
+    const long total = (long)n_rows * ds.choff[n_blocks] * ds.D;
+    const unsigned block = 256;
+    if ((total + block - 1) / block >= (1ll << 31)) return csmpn_fail(CSMPN_ERR_INVALID, "too many rows");
+    hipLaunchKernelGGL(simplex_rows_kernel, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, (hipStream_t)stream,
+                       ds, verts, (long)n_rows, (long)n_feature_rows, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "simplex rows: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_readout_mse_forward(int n, const float* x, const float* weight, int32_t weight_stride, const float* bias,
+                              int64_t n_rows, int32_t channels, const int32_t* graph_ptr, int64_t n_graphs,
+                              const float* target, float* pred, float* loss, float* channel_sums, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_graphs <= 0) return CSMPN_OK;
+    if (!x || !weight || !graph_ptr || !target || !pred || !loss || !channel_sums || channels < 1 || weight_stride < 1 || n_rows < 0)
+        return csmpn_fail(CSMPN_ERR_INVALID, "bad arguments");
+    hipLaunchKernelGGL(readout_fwd_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, weight,
+                       (int)weight_stride, bias, (int)channels, 1 << n, (const int*)graph_ptr, target, pred, loss, channel_sums);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "readout forward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_readout_mse_backward(int n, const float* weight, int32_t weight_stride, int64_t n_rows, int32_t channels,
+                               const int32_t* graph_ptr, int64_t n_graphs, const float* coef, float* gx, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_rows <= 0) return CSMPN_OK;
+    if (!weight || !graph_ptr || !coef || !gx || channels < 1 || n_graphs < 1) return csmpn_fail(CSMPN_ERR_INVALID, "bad arguments");
+    const long total = (long)n_rows * channels * (1 << n);
+    const unsigned block = 256;
+    hipLaunchKernelGGL(readout_bwd_kernel, dim3((unsigned)((total + block - 1) / block)), dim3(block), 0, (hipStream_t)stream,
+                       weight, (int)weight_stride, (int)channels, 1 << n, (const int*)graph_ptr, (int)n_graphs, coef,
+                       (long)n_rows, gx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "readout backward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+}  // extern "C"

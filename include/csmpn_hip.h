@@ -221,6 +221,32 @@ int csmpn_egcl_node_backward(const float* metric_host, int n, const csmpn_block_
                              int32_t residual, int64_t n_nodes, const float* g_out, float* gh, float* g_agg,
                              float* g_node_attr, const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* Input rows of the simplex feature embedding (hulls_cssmpnn.py:96-125, md17_cssmpnn.py:85-120):
+ * row r lists verts_per_row vertices (rows of the per-simplex feature tensors) in ONE vertex order;
+ * block b contributes verts_per_row * channels_b channels (vertex by vertex), embedded at its grade:
+ *   out[r][off_b + v * K_b + k][gstart(grade_b) + t] = blocks[b].data[verts[r][v]][k][t],  0 elsewhere.
+ * out [n_rows, sum_b verts_per_row * K_b, 2^n]; blocks[b].data [n_feature_rows, K_b, C(n, grade_b)]. */
+typedef struct csmpn_vertex_block {
+    const float* data;
+    int32_t channels;
+    int32_t grade;
+} csmpn_vertex_block;
+int csmpn_simplex_rows(int n, const csmpn_vertex_block* blocks, int n_blocks, const int64_t* verts, int64_t n_rows,
+                       int32_t verts_per_row, int64_t n_feature_rows, float* out, void* stream);
+
+/* Scalar readout + loss of the convex-hulls model (hulls_cssmpnn.py:93,155-164):
+ *   pred_g = mean_{s in graph g} (sum_c weight[c * weight_stride] * x[s][c][0]) + bias,  loss_g = (pred_g - target_g)^2
+ * weight points at MVLinear.weight[0] (out_features = 1; weight_stride = n+1 with subspaces, else 1),
+ * bias at MVLinear.bias or NULL. The simplices of graph g are rows [graph_ptr[g], graph_ptr[g+1]).
+ * channel_sums [n_graphs, channels] receives sum_s x[s][c][0] (the weight gradient is coef^T channel_sums).
+ * backward: gx[s][c][d] = (d == 0) ? coef[graph(s)] * weight[c * weight_stride] : 0 (overwritten), with
+ * coef_g = dL/dloss_g * 2 (pred_g - target_g) / max(count_g, 1) computed by the caller. */
+int csmpn_readout_mse_forward(int n, const float* x, const float* weight, int32_t weight_stride, const float* bias,
+                              int64_t n_rows, int32_t channels, const int32_t* graph_ptr, int64_t n_graphs,
+                              const float* target, float* pred, float* loss, float* channel_sums, void* stream);
+int csmpn_readout_mse_backward(int n, const float* weight, int32_t weight_stride, int64_t n_rows, int32_t channels,
+                               const int32_t* graph_ptr, int64_t n_graphs, const float* coef, float* gx, void* stream);
+
 /* Last error message of the calling thread (never NULL). */
 const char* csmpn_last_error(void);
 

@@ -210,3 +210,97 @@ def test_hulls_adam_trajectory_gpu(pkg):
     tol = 1e-5 + (2e-3 - 1e-5) * np.arange(len(ref)) / max(len(ref) - 1, 1)
     assert np.all(np.abs(got - ref) <= tol * np.maximum(np.abs(ref), 1e-3)), (got, ref)
     assert got[-1] < got[0]
+
+
+def _hull_batch(pkg, seed, n_graphs=4, scale=1.0, device=None):
+    from csmpn.data import complexes as cx
+    rng = np.random.default_rng(seed)
+    gs = []
+    for _ in range(n_graphs):
+        pts = rng.standard_normal((8, 5)).astype(np.float32)
+        c = cx.hulls_example(pts)
+        # same complex, scaled coordinates: the topology of the batch does not depend on `scale`
+        c.features["input"] = c.features["input"] * scale
+        c.labels["target"] = c.labels["target"] * scale ** 5
+        gs.append(c)
+    b = cx.collate(gs)
+    return b.to(device) if device is not None else b
+
+
+@pytest.mark.gpu
+def test_fused_embedding_and_readout_match_composed_ops(pkg):
+    """csmpn_simplex_rows and csmpn_readout_mse_* against the same stages composed from tensor indexing and the
+    standalone MVLinear: forward values and every gradient."""
+    from csmpn.models import simplicial_mpnn as M
+    from csmpn_hip import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = M.HullsSimplicialMPNN(hidden_features=8, num_layers=1).to(dev)
+    batch = _hull_batch(pkg, 5, device=dev)
+    plan = batch.plan(2)
+    # embedding rows: gather + grade-1 embedding, all vertex orders
+    inp = batch.input.unsqueeze(1)
+    for d in range(3):
+        pv = plan["verts"][d]
+        got = ops.simplex_rows(5, [(inp, 1)], pv)
+        g = inp[pv]
+        want = model.algebra.embed_grade(g.reshape(g.shape[0], (d + 1), 5), 1)
+        assert torch.equal(got, want)
+    # two blocks of different grades and widths (the md17 layout)
+    pos, chg = torch.randn(inp.shape[0], 3, 3, device=dev), torch.randn(inp.shape[0], 2, 1, device=dev)
+    alg3 = pkg.CliffordAlgebra((1.0, 1.0, 1.0)).to(dev)
+    pv = plan["verts"][2]
+    got = ops.simplex_rows(3, [(pos, 1), (chg, 0)], pv)
+    want = torch.cat([alg3.embed_grade(pos[pv].reshape(pv.shape[0], 9, 3), 1),
+                      alg3.embed_grade(chg[pv].reshape(pv.shape[0], 6, 1), 0)], dim=1)
+    assert torch.equal(got, want)
+    # readout + loss
+    x = torch.randn(batch.x_ind.shape[0], 8, 32, device=dev, requires_grad=True)
+    head = model.projection[0]
+    with torch.no_grad():
+        head.bias.fill_(0.3)
+    ptr = batch.x_ind_ptr.to(torch.int32)
+    wl = torch.randn(batch.num_graphs, device=dev)
+    loss, pred = ops.readout_mse(x, head.weight, head.bias, ptr, batch.target, 5)
+    (loss * wl).sum().backward()
+    got = [loss.detach().clone(), pred.clone(), x.grad.clone(), head.weight.grad.clone(), head.bias.grad.clone()]
+    x.grad = None; head.weight.grad = None; head.bias.grad = None
+    p2 = M.segment_mean(head(x)[:, :, 0], batch.x_ind_batch, batch.num_graphs).squeeze(-1)
+    l2 = (p2 - batch.target) ** 2
+    (l2 * wl).sum().backward()
+    want = [l2.detach(), p2.detach(), x.grad, head.weight.grad, head.bias.grad]
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) <= 1e-5 * max(float(b.abs().max()), 1e-6), (a, b)
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_matches_eager(pkg):
+    """The whole hulls training step (embedding, 3 x EGCL forward + backward, readout, loss, Adam) replayed from one
+    HIP graph follows the eager trajectory; features are refilled between replays."""
+    import copy
+    from csmpn.models import simplicial_mpnn as M
+    from csmpn_hip.graphed import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    model_e = M.HullsSimplicialMPNN(hidden_features=28, num_layers=3).to(dev)
+    model_g = copy.deepcopy(model_e)
+    b0, b1 = _hull_batch(pkg, 9, device=dev), _hull_batch(pkg, 9, scale=1.1, device=dev)
+    feats = [{"input": b0.input.clone(), "target": b0.target.clone()}, {"input": b1.input.clone(), "target": b1.target.clone()}]
+    opt_e = torch.optim.Adam(model_e.parameters(), lr=1e-3)
+    opt_g = torch.optim.Adam(model_g.parameters(), lr=1e-3, capturable=True)
+    eager, graphed = [], []
+    batches = [b0, b1]
+    for step in range(6):
+        loss, _ = model_e(batches[step % 2])
+        opt_e.zero_grad(set_to_none=True)
+        loss.backward()
+        opt_e.step()
+        eager.append(float(loss.detach()))
+    static = _hull_batch(pkg, 9, device=dev)
+    gs = GraphedTrainStep(model_g, opt_g, static, ["input", "target"])
+    for step in range(6):
+        graphed.append(float(gs.step(feats[step % 2]).detach()))
+    eager, graphed = np.asarray(eager), np.asarray(graphed)
+    assert np.all(np.abs(eager - graphed) <= 1e-3 * np.maximum(np.abs(eager), 1e-3)), (eager, graphed)
+    for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+        assert float((pe - pg).detach().abs().max()) <= 1e-3 * max(float(pe.detach().abs().max()), 1e-2)

@@ -1,0 +1,75 @@
+"""Whole-model training step, eager vs one HIP graph (csmpn_hip.graphed.GraphedTrainStep).
+
+    python tools/model_step_bench.py [--batch 16] [--steps 30]
+
+The convex-hulls task model at the reference's configuration (csmpn/configs/hulls.yaml: Cl(5,0), 28
+hidden channels, 3 layers, batch size 16, 8 points per hull, Adam lr 1e-3) on synthetic hulls. Prints one
+JSON line with the step times and the simplices / adjacencies of the batch.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "clifford-group-equivariant-simplicial-message-passing-networks_amd"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--points", type=int, default=8)
+    args = ap.parse_args()
+    importlib.import_module(PKG)
+    from csmpn.data import complexes as cx
+    from csmpn.models import simplicial_mpnn as M
+    from csmpn_hip.graphed import GraphedTrainStep
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(0)
+    batch = cx.collate([cx.hulls_example(rng.standard_normal((args.points, 5)).astype(np.float32))
+                        for _ in range(args.batch)]).to(dev)
+    torch.manual_seed(0)
+    model = M.HullsSimplicialMPNN().to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+    def eager():
+        opt.zero_grad(set_to_none=False)
+        loss, _ = model(batch)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(5):
+        eager()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eager()
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+
+    gs = GraphedTrainStep(model, opt, batch, ["input", "target"])
+    for _ in range(5):
+        gs.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gs.step()
+    torch.cuda.synchronize()
+    graph_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    print(json.dumps({"model": "hulls (Cl(5,0), 28 channels, 3 layers)", "graphs_per_batch": args.batch,
+                      "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
+                      "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
+                      "loss": float(gs.loss.detach())}))
+
+
+if __name__ == "__main__":
+    main()
