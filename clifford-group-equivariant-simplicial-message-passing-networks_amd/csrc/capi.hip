@@ -15,6 +15,7 @@
 #include "cemlp_kernel.hpp"
 #include "launch.hpp"
 #include "rl_launch.hpp"
+#include "pl_launch.hpp"
 
 using namespace csmpn;
 
@@ -526,10 +527,44 @@ bool rl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return true;
 }
 
+// parity-lane kernels (cemlp_pl.hpp): Cl(5,0) / Cl(4,1), two blocks of 8 channels, the EGCL attribute widths of S3
+bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* i0) {
+    static const bool off = getenv("CSMPN_NO_PL") && atoi(getenv("CSMPN_NO_PL"));
+    if (off || (id != ALG_N5 && id != ALG_N5M)) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    for (int k = 0; k < C.nblk; ++k) {
+        if (C.b[k].O != 8 || !C.b[k].w1_sub) return false;
+        if (k > 0 && C.b[k].I != 8) return false;
+    }
+    if (mode == MODE_EDGE && io.seg[0].ch != 8) return false;
+    if (mode == MODE_NODE && (io.seg[0].ch != 8 || io.seg[1].ch != 8)) return false;
+    if (mode != MODE_EDGE && mode != MODE_NODE) return false;
+    if (bwd && !io.saved) return false;
+    if (io.row_store) return false;   // the deterministic mode is the row-per-lane kernels' (atomic-free parameter sums)
+    *i0 = C.b[0].I;
+    return id == ALG_N5 ? has_cemlp_pl_n5(mode, C.nblk, 8, *i0) : has_cemlp_pl_n5m(mode, C.nblk, 8, *i0);
+}
+
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    {
+        int i0 = 0;
+        if (pl_eligible(id, plan, mode, bwd, io, &i0)) {
+            const long tiles = (io.rows + 3) / 4;          // 4 rows per wave tile
+            const long cap = bwd ? kPlMaxBwdGroups : 512;  // one / two 4-wave workgroups per CU
+            const long groups = (tiles + 3) / 4;
+            const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            bool handled = false;
+            static const bool debug_pl = getenv("CSMPN_DEBUG") != nullptr;
+            if (debug_pl) fprintf(stderr, "[csmpn] pl mode=%d bwd=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, i0, grid, io.rows);
+            if (id == ALG_N5) HIP_TRY(launch_cemlp_pl_n5(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
+            else HIP_TRY(launch_cemlp_pl_n5m(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
+            if (handled) return CSMPN_OK;
+        }
+    }
     {
         int channels = 0, i0 = 0;
         if (rl_eligible(id, plan, mode, bwd, io, &channels, &i0)) {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 profiling recipe (run on the GPU box through gpurun from the repo root):
-#   tools/profile_r02.sh <tag>
+#   tools/profile_r02.sh <tag> [workload]      (workload S1 | S2 | S3, default S1; use the workload as the tag)
 # Kernel trace + stats first, PMC counters in their own passes (no trace domains), then
 # tools/summarize_profile.py writes profiles/r02_<tag>_kernel_stats.csv and
 # profiles/r02_<tag>_pmc_summary.json into gpurun_out/ for copying into profiles/.
@@ -11,7 +11,8 @@ TAG=$1
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT
 mkdir -p $OUT
-B="python3 bench.py --no-cpu-baseline --no-graph"
+WL=${2:-S1}
+B="python3 bench.py --no-cpu-baseline --no-graph --workload $WL"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmc1 -- $B --steps 3 --warmup 2 > $OUT/bench_pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_MISC --output-format csv -d $OUT/pmc2 -- $B --steps 3 --warmup 2 > $OUT/bench_pmc2.log 2>&1

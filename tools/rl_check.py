@@ -8,13 +8,14 @@ from oracle import ref_path as O
 from csmpn_hip import ops
 dev = torch.device("cuda:0")
 N, E, C = int(os.environ.get("N", 10000)), int(os.environ.get("E", 100000)), 8
+METRIC = {"cl30": [1.0, 1.0, 1.0], "cl50": [1.0] * 5, "cl41": [1.0, 1.0, 1.0, 1.0, -1.0]}[os.environ.get("ALG", "cl30")]
 torch.manual_seed(0)
-layer = pkg.EGCL(pkg.CliffordAlgebra((1.0, 1.0, 1.0)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
-h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), N, E, C, seed=0))
+layer = pkg.EGCL(pkg.CliffordAlgebra(tuple(METRIC)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
+h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(METRIC), N, E, C, seed=0))
 be, spec = ops.HipBackend, layer.spec()
 csr = ops.get_csr(ei, N)
 pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
-gout = torch.randn(N, C, 8, device=dev)
+gout = torch.randn(N, C, 1 << len(METRIC), device=dev)
 agg, st_e = be.edge_forward(spec, csr, h, ea, pe)
 out, st_n = be.node_forward(spec, csr.deg, h, agg, na, pn)
 gh, g_agg, _, gn = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, st_n)
