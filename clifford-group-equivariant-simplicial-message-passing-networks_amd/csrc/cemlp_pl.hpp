@@ -52,6 +52,15 @@ CSMPN_DEV float pl_chan_sum(float v) {
     return v;
 }
 CSMPN_DEV f4 pl_ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+// Ordering point for the instruction scheduler. A bare sched_barrier does not order pure arithmetic (the
+// selection DAG sinks it below a run of barriers and the whole phase becomes one region with hundreds of
+// values in flight); passing the values just produced through an empty volatile asm ties them to the barrier.
+template <int LO, int HI, int N>
+CSMPN_DEV void pl_pin(float (&a)[N]) {
+#pragma unroll
+    for (int i = LO; i < HI; ++i) asm volatile("" : "+v"(a[i]));
+    CSMPN_PHASE();
+}
 CSMPN_DEV float smooth_abs_sqrt1(float q) { return sqrt_pos(sqrt_pos(q * q + kSmooth)); }
 
 // ---------------------------------------------------------------------------------
@@ -177,7 +186,7 @@ CSMPN_DEV void pl_linear(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL
             constexpr int j = decltype(jj)::value;
             acc[j] = __builtin_fmaf(w[decltype(r)::value][P::t.cls[j]], pl_rot<decltype(r)::value>(x[j]), acc[j]);
         });
-        CSMPN_PHASE();
+        pl_pin<0, DL>(acc);
     });
 }
 // two matrices applied to the same input (linear_right and linear_left): the rotated copies are shared
@@ -199,7 +208,8 @@ CSMPN_DEV void pl_linear2(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL]
             accA[j] = __builtin_fmaf(wa[P::t.cls[j]], t, accA[j]);
             accB[j] = __builtin_fmaf(wb[P::t.cls[j]], t, accB[j]);
         });
-        CSMPN_PHASE();
+        pl_pin<0, DL>(accA);
+        pl_pin<0, DL>(accB);
     });
 }
 
@@ -320,7 +330,7 @@ CSMPN_DEV void pl_weighted_gp(float (&out)[PS<ALG>::DL], const float (&z)[PS<ALG
         });
 #pragma unroll
         for (int t = 0; t < nc; ++t) gp[c0 + t] += wA * tA[t] + wB * tB[t];
-        CSMPN_PHASE();   // one path class per scheduling region: bounds the accumulators in flight
+        pl_pin<c0, c0 + nc>(gp);   // one path class per scheduling region: bounds the accumulators in flight
     });
     pl_tilde<ALG>(gp, ge);
 #pragma unroll
@@ -392,7 +402,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlSta
         // even lanes: K1 -> w00 (product A), K3 -> w01 (product B); odd lanes: K3 -> w10 (A), K1 -> w11 (B)
         gwA[q] += ge.s ? k3 : k1;
         gwB[q] += ge.s ? k1 : k3;
-        CSMPN_PHASE();
+        asm volatile("" : "+v"(gwA[q]), "+v"(gwB[q]));
+        pl_pin<a0, a0 + na>(gzt);
     });
     pl_tilde<ALG>(gzt, ge);
 #pragma unroll
@@ -447,7 +458,7 @@ CSMPN_DEV void pl_weighted_gp_bwd_r(const float (&ggp)[PS<ALG>::DL], const PlSta
         });
 #pragma unroll
         for (int t = 0; t < nb; ++t) grt[b0 + t] += v1 * V1[t] + v2 * V2[t];
-        CSMPN_PHASE();
+        pl_pin<b0, b0 + nb>(grt);
     });
     pl_tilde<ALG>(grt, ge);
 #pragma unroll
@@ -724,6 +735,9 @@ CSMPN_DEV void pl_copy_rows(const float* sc, int rs, int ncol, int lane, F&& out
 // and, when SUB, subtraction from table[t_sub[row]]. Negative targets are skipped. t_* live in lane 16 r of row r.
 template <int ROWLEN, bool SUB>
 CSMPN_DEV void pl_scatter(const float* sc, int rs, int t_add, int t_sub, float* table, int lane) {
+#ifdef PL_X_NOSCAT
+    return;
+#endif
     static_for<0, ROWLEN / 64>([&](auto cc) {
         const int col = 64 * decltype(cc)::value + lane;
         float val[kPlRows];
