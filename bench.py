@@ -58,10 +58,10 @@ def algorithmic_bytes(C, D, A=6, T=3):
 
 def kernel_of(stage, name):
     """Does the rocprofv3 kernel name belong to this stage? (MODE 1 = edge, 2 = node; last template
-    argument = backward.) cemlp_rl_kernel<Alg, NOG, MODE, NBLK, I0, BWD>, cemlp_kernel<Alg, MODE, ...>,
-    cemlp_ps_kernel<Alg, MODE, BWD>."""
+    argument = backward.) cemlp_rl_kernel<Alg, NOG, MODE, NBLK, I0, BWD>, cemlp_pl_kernel<Alg, MODE, NBLK, I0, BWD>,
+    cemlp_kernel<Alg, MODE, ...>, cemlp_ps_kernel<Alg, MODE, BWD>."""
     import re
-    m = re.search(r"cemlp(_rl|_ps)?_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+    m = re.search(r"cemlp(_rl|_ps|_pl)?_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
     if not m:
         return False
     args = [a.strip() for a in m.group(2).split(",")]
@@ -108,8 +108,8 @@ def make_inputs(metric, C, N, E_total, lo, hi, device):
 
 def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0):
     """The reference CPU path (oracle restatement: dense-einsum formulation, PyTorch CPU)
-    on a BOUNDED sample of the same workload: the first E_s edges of the S1 edge list over
-    the same nodes, fwd+bwd. E_s is sized from a small probe so that the timed runs take
+    on a BOUNDED sample of the same workload: the first E_s edges of the edge list, node ids folded
+    onto the first N_s = N E_s / E nodes (same edge / node ratio as the workload), fwd+bwd. E_s is sized from a small probe so that the timed runs take
     about `budget_s` seconds; threads = min(host cores, 32) (more threads make the many
     small einsum/bmm calls slower, measured: 256 threads -> 235 s per 100k edges)."""
     from oracle import ref_path as O
@@ -119,10 +119,17 @@ def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0):
     h, ei, ea, na = cpu_inputs
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in state.items()}
 
+    E_all, N_all = ei.shape[1], h.shape[0]
+
+    def nodes_for(ne):   # the sample keeps the workload's edge / node ratio (node ids folded onto the first N_s)
+        return N_all if ne >= E_all else max(16, -(-N_all * ne // E_all))
+
     def run(ne):
-        hh = h.clone().requires_grad_(True)
+        ns = nodes_for(ne)
+        hh = h[:ns].clone().requires_grad_(True)
+        es = ei[:, :ne] if ns == N_all else ei[:, :ne] % ns
         t0 = time.perf_counter()
-        y = O.egcl(alg, hh, ei[:, :ne], ea[:ne], na, p, aggr="mean")
+        y = O.egcl(alg, hh, es, ea[:ne], na[:ns], p, aggr="mean")
         y.backward(torch.ones_like(y))
         dt = time.perf_counter() - t0
         for v in p.values():
@@ -156,8 +163,9 @@ def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0):
         twin = {"error": f"{type(exc).__name__}: {exc}"}
     return {"value": ne / med, "unit": "edges/s", "cores": cores, "kind": "port", "host_cores": os.cpu_count(),
             "strong_cpu_twin": twin,
-            "sample": f"{'all' if ne == ei.shape[1] else 'first'} {ne} of {ei.shape[1]} edges over the same "
-                      f"{h.shape[0]} nodes, fwd+bwd, median of {reps} runs ({med:.3f} s each), torch "
+            "sample": f"{'all' if ne == ei.shape[1] else 'first'} {ne} of {ei.shape[1]} edges over "
+                      f"{'the same' if ne == ei.shape[1] else 'the first'} {nodes_for(ne)} of {h.shape[0]} nodes "
+                      f"(same edge/node ratio), fwd+bwd, median of {reps} runs ({med:.3f} s each), torch "
                       f"{torch.__version__} CPU threads={cores} of {os.cpu_count()} host cores"}
 
 
@@ -349,7 +357,7 @@ def main():
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
         bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
         roofline = {
-            "bound": "hbm", "kernel": f"{dom} (cemlp_rl_kernel when the layer is 8 channels of Cl(3,0), else cemlp_kernel / cemlp_ps_kernel)",
+            "bound": "hbm", "kernel": f"{dom} (cemlp_rl_kernel: Cl(3,0) 8|16 channels; cemlp_pl_kernel: Cl(5,0)|Cl(4,1) 8 channels; else cemlp_kernel / cemlp_ps_kernel)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(dom, args.workload),
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
