@@ -261,7 +261,8 @@ def test_egcl_golden_can_fail(pkg, golden_dir, name):
             _compare_egcl_fixture(g, variant, mutated(key, fn), False)
 
 
-def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_scale=None, slack=None, max_yard=None):
+def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_scale=None, slack=None, max_yard=None,
+                      attr_grad=False):
     """Seeded synthetic complex; HIP layer vs the float64 oracle with identical parameters.
 
     Indefinite metrics (Cl(4,1)) make the backward ill-conditioned on random inputs: the
@@ -291,17 +292,20 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_sc
     layer.load_state_dict(sd, strict=True)
     layer = layer.to(dev())
     hd = h.to(dev()).requires_grad_(True)
-    y = layer(hd, ei.to(dev()), ea.to(dev()), na.to(dev()))
+    ead, nad = ea.to(dev()).requires_grad_(attr_grad), na.to(dev()).requires_grad_(attr_grad)
+    y = layer(hd, ei.to(dev()), ead, nad)
     gout = torch.randn(y.shape, generator=gen)
     (y * gout.to(dev())).sum().backward()
     p64 = {k: v.double().requires_grad_(True) for k, v in p.items()}
     h64 = h.double().requires_grad_(True)
-    y64 = O.egcl(oa, h64, ei, ea.double(), na.double(), p64, aggr=aggr, residual=residual)
+    ea64, na64 = ea.double().requires_grad_(attr_grad), na.double().requires_grad_(attr_grad)
+    y64 = O.egcl(oa, h64, ei, ea64, na64, p64, aggr=aggr, residual=residual)
     (y64 * gout.double()).sum().backward()
     # float32 oracle run as the yardstick
     p32 = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     h32 = h.clone().requires_grad_(True)
-    y32 = O.egcl(o32, h32, ei, ea, na, p32, aggr=aggr, residual=residual)
+    ea32, na32 = ea.clone().requires_grad_(attr_grad), na.clone().requires_grad_(attr_grad)
+    y32 = O.egcl(o32, h32, ei, ea32, na32, p32, aggr=aggr, residual=residual)
     (y32 * gout).sum().backward()
     if max_yard is not None:
         # the case must really be held to ~1e-5: the reference-formulation float32 run itself is this close
@@ -312,7 +316,23 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_sc
             "gh": check("gh", hd.grad.cpu().numpy(), h64.grad.numpy(), h32.grad.numpy(), slack=slack)}
     for k, prm in layer.named_parameters():
         errs[k] = check("g." + k, prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy(), slack=slack)
+    if attr_grad:
+        if E > 0:
+            errs["g_ea"] = check("g_edge_attr", ead.grad.cpu().numpy(), ea64.grad.numpy(), ea32.grad.numpy(), slack=slack)
+        errs["g_na"] = check("g_node_attr", nad.grad.cpu().numpy(), na64.grad.numpy(), na32.grad.numpy(), slack=slack)
     return errs
+
+
+# the shapes served by the row-per-lane (Cl(3,0), 8 / 16 channels) and parity-lane (Cl(5,0), Cl(4,1), 8 channels)
+# kernels: tile tails (rows not a multiple of the 32 / 16 / 4 rows of a wave tile), fewer rows than one tile,
+# aggr = sum, no residual, attribute gradients
+@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0, 1.0, 1.0), 16), ((1.0,) * 5, 8),
+                                      ((1.0, 1.0, 1.0, 1.0, -1.0), 8)])
+@pytest.mark.parametrize("N,E,aggr,residual", [(2, 1, "mean", True), (5, 3, "sum", True), (37, 101, "mean", False),
+                                               (64, 258, "sum", True), (130, 1027, "mean", True)])
+def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
+    _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=N + E, residual=residual,
+                      neg_scale=0.02 if min(metric) < 0 else None, attr_grad=True)
 
 
 @pytest.mark.parametrize("metric,C,hidden,aggr", [
