@@ -16,6 +16,7 @@
 #include "launch.hpp"
 #include "rl_launch.hpp"
 #include "pl_launch.hpp"
+#include "plw_launch.hpp"
 
 using namespace csmpn;
 
@@ -501,6 +502,16 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     return cemlp_rl_partial_floats_n3(nblk, ch, blocks[0].in_features) * sizeof(float) * kRlPartialGroups;
 }
 
+// bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
+// (never together with the row-per-lane region: different algebras). Upper bound over the entry points.
+size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n != 5 || nblk != 2) return 0;
+    const int ch = blocks[0].out_features;
+    if (ch <= 8 || ch > 32 || blocks[1].out_features != ch || blocks[1].in_features != ch) return 0;
+    const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
+    return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256;
+}
+
 // Row-per-lane kernels (cemlp_rl.hpp): every block 8 channels wide, MVLinear with per-grade
 // weights, and (backward of a two-block CEMLP) the block-1 input saved by the forward.
 // CSMPN_NO_RL=1 keeps the generic kernels (A/B measurements, parity tests of both paths).
@@ -546,10 +557,52 @@ bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return id == ALG_N5 ? has_cemlp_pl_n5(mode, C.nblk, 8, *i0) : has_cemlp_pl_n5m(mode, C.nblk, 8, *i0);
 }
 
+// wide parity-lane kernels (cemlp_plw.hpp): Cl(5,0), two blocks of 9 .. 32 channels, EGCL edge / node programs
+bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
+    static const bool off = getenv("CSMPN_NO_PLW") && atoi(getenv("CSMPN_NO_PLW"));
+    if (off || id != ALG_N5) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    const int ch = C.b[0].O;
+    if (ch <= 8 || ch > 32 || C.b[1].O != ch || C.b[1].I != ch || !C.b[0].w1_sub || !C.b[1].w1_sub) return false;
+    int na = 0;
+    if (mode == MODE_EDGE) {
+        if (io.seg[0].ch != ch) return false;
+        na = io.nseg > 1 ? io.seg[1].ch : 0;
+    } else if (mode == MODE_NODE) {
+        if (io.seg[0].ch != ch || io.seg[1].ch != ch) return false;
+        na = io.nseg > 2 ? io.seg[2].ch : 0;
+    } else {
+        return false;
+    }
+    if (C.b[0].I != (mode == MODE_EDGE ? ch : 2 * ch) + na) return false;
+    if (io.row_store) return false;
+    const size_t tf = cemlp_plw_table_floats_n5(mode, ch, na);
+    if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + 512) return false;
+    if (bwd && (!io.saved || !has_cemlp_plw_bwd_n5(mode, ch, na))) return false;
+    *channels = ch;
+    *attr = na;
+    return true;
+}
+
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    {
+        int channels = 0, attr = 0;
+        if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
+            const long tiles = (io.rows + 3) / 4;          // one 4-row tile per workgroup iteration
+            const unsigned grid = (unsigned)(tiles < kPlwMaxGroups ? tiles : kPlwMaxGroups);
+            const size_t tb = cemlp_plw_table_floats_n5(mode, channels, attr) * sizeof(float);
+            float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
+            bool handled = false;
+            static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;
+            if (debug_plw) fprintf(stderr, "[csmpn] plw mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
+            HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            if (handled) return CSMPN_OK;
+        }
+    }
     {
         int i0 = 0;
         if (pl_eligible(id, plan, mode, bwd, io, &i0)) {
@@ -817,7 +870,7 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
         const size_t s2 = (size_t)kGlobalTileGrid * grt * Lf.total * 4;
         scratch = s2 > scratch ? s2 : scratch;
     }
-    return ((bytes + scratch + 15) & ~(size_t)15) + rl_partial_bytes(n, blocks, n_blocks) + 16;
+    return ((bytes + scratch + 15) & ~(size_t)15) + rl_partial_bytes(n, blocks, n_blocks) + plw_table_bytes(n, blocks, n_blocks) + 16;
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,

@@ -121,6 +121,8 @@ struct RowIO {
     // that a segmented reduction sums afterwards in a fixed order
     int row_store;
     int pad3_;
+    const float* plw_tabs;  // wide parity-lane kernels (cemlp_plw.hpp): rotation tables packed into the workspace
+    float* plw_g1;          // ... backward: d/d(block-1 input) rows handed from the block-1 launch to the block-0 launch
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

@@ -1,0 +1,412 @@
+// Parity-lane row program for WIDE D = 32 layers (9 .. 32 channels; the convex-hulls width is 28 channels of
+// Cl(5,0)): the distribution of cemlp_pl.hpp with one WAVE per group of 8 channels.
+//
+//   workgroup = NG waves on the same 4-row tile; wave g owns channels 8g .. 8g+7;
+//   lane = (row q, channel c of the group, blade parity s) as in cemlp_pl.hpp: a tensor is float t[16].
+//
+// Wave-local (no communication): gates, normalisation, the geometric product and its backward, the per-channel
+// parameter sums. Across the groups:
+//   dense mixing    y_og = sum_ig M[og][ig] x_ig. The input groups travel through an LDS exchange buffer
+//                   ([group][slot][lane], conflict-free); every (og, ig) block is the 8-rotation / 16-slot VALU
+//                   product of cemlp_pl.hpp with its 24 weights per lane read as 6 x 16 bytes from rotation tables
+//                   packed once per launch into the workspace (plw_pack_kernel; L2-resident - the weights of a
+//                   28-channel CEMLP, 134 KB, do not fit LDS beside the gradient sums);
+//   LayerNorm mean  one float per (row, group) through LDS;
+//   weight gradients v_mfma_f32_16x16x4_f32 as in cemlp_pl.hpp with B = the input group read from the exchange buffer:
+//                   3 x f4 accumulators per (og, ig) block in AGPRs. The backward is launched once per block
+//                   (BLK = 1, then BLK = 0, d/d(block-1 input) handed over through a row scratch) so that one
+//                   launch holds the accumulators of one block only.
+// Block 0 reads its input "chunks" (8 channels of one input segment: h[dst] - h[src], attributes, aggregate, ...)
+// straight from global memory in every wave, so input segments need no alignment to the groups.
+#pragma once
+#include "cemlp_pl.hpp"
+
+namespace csmpn {
+
+// compile-time description of one kernel family member
+template <class ALG, int NG_, int C_, int MODE_, int NA_>
+struct PlwCfg {
+    using P = PS<ALG>;
+    static constexpr int NG = NG_, C = C_, MODE = MODE_, NA = NA_, CP = 8 * NG_;
+    static constexpr int D = ALG::D, DL = P::DL, GC = P::GC, G = ALG::G, NP = ALG::P, QP = P::QP, N = ALG::n;
+    static constexpr int ROW = C * D;
+    static_assert(C > 8 * (NG - 1) && C <= 8 * NG, "NG = ceil(C / 8)");
+    static_assert(NA >= 0 && NA <= 8, "attribute channels fit one chunk");
+    static_assert(MODE == MODE_EDGE || MODE == MODE_NODE, "edge / node programs");
+    // input chunks of block 0: (first channel in the concatenated input, valid channels)
+    static constexpr int NSEG = MODE == MODE_EDGE ? 1 : 2;                  // full-width segments in front of the attributes
+    static constexpr int NCH0 = NSEG * NG + (NA > 0 ? 1 : 0);
+    static constexpr int I0 = NSEG * C + NA;
+    static constexpr int chunk_base(int j) { return j < NSEG * NG ? (j / NG) * C + 8 * (j % NG) : NSEG * C; }
+    static constexpr int chunk_valid(int j) {
+        return j < NSEG * NG ? (C - 8 * (j % NG) < 8 ? C - 8 * (j % NG) : 8) : NA;
+    }
+    static constexpr int Iof(int k) { return k == 0 ? I0 : C; }
+    static constexpr int nch(int k) { return k == 0 ? NCH0 : NG; }
+    // rotation tables in the workspace (floats): pair (a, b) of a table with NB columns at ((a * NB + b) * 16 + n) * 24
+    static constexpr int PAIR = 16 * 24;
+    static constexpr int t_W1(int k) { return k == 0 ? 0 : tab_blk(0); }            // [og][chunk]
+    static constexpr int t_W1t(int k) { return t_W1(k) + NG * nch(k) * PAIR; }      // [chunk][og]
+    static constexpr int t_WR(int k) { return t_W1t(k) + NG * nch(k) * PAIR; }      // [og][ig]
+    static constexpr int t_WRt(int k) { return t_WR(k) + NG * NG * PAIR; }          // [ig][og]
+    static constexpr int t_WL(int k) { return t_WRt(k) + NG * NG * PAIR; }
+    static constexpr int t_WLt(int k) { return t_WL(k) + NG * NG * PAIR; }
+    static constexpr int tab_blk(int k) { return (2 * NG * nch(k) + 4 * NG * NG) * PAIR; }
+    static constexpr int tab_total = tab_blk(0) + tab_blk(1);
+    // LDS (floats)
+    static constexpr int par_floats = 3 * CP + 3 * CP * G + CP * NP;
+    static constexpr int p_b1(int k) { return k * par_floats; }
+    static constexpr int p_bL(int k) { return p_b1(k) + CP; }
+    static constexpr int p_la(int k) { return p_bL(k) + CP; }
+    static constexpr int p_sa(int k) { return p_la(k) + CP; }
+    static constexpr int p_sb(int k) { return p_sa(k) + CP * G; }
+    static constexpr int p_sg(int k) { return p_sb(k) + CP * G; }
+    static constexpr int p_w(int k) { return p_sg(k) + CP * G; }
+    static constexpr int store_total = 2 * par_floats;
+    static constexpr int XB = NG * DL * 64;                 // one exchange buffer [group][slot][lane]
+    static constexpr int x_off(int b) { return store_total + b * XB; }
+    static constexpr int NXB = 3;
+    static constexpr int ln_off = x_off(NXB);               // [2][NG][4 rows]
+    static constexpr int RS = ROW + 4;
+    static constexpr int st_off = ln_off + 2 * NG * kPlRows + 8;   // staging tile [4 rows][ROW + 4]
+    static constexpr int fwd_total = st_off + kPlRows * RS;
+    static constexpr int n_sums = 3 + 3 * GC + 2 * QP;
+    static constexpr int tot_off = fwd_total;               // backward: lane-private running sums [slot][thread]
+    static constexpr int bwd_total = tot_off + n_sums * 64 * NG;
+};
+
+// ---------------------------------------------------------------------------------
+// rotation tables -> workspace. One thread per table float.
+template <class CF, class ALG>
+__global__ void plw_pack_kernel(const DevCemlp Cd, float* tabs) {
+    constexpr int NG = CF::NG, C = CF::C, G = CF::G, GC = CF::GC, PAIR = CF::PAIR;
+    const int probe = pl_dpp_i<0x122>((int)(threadIdx.x & 15));
+    const int dir = (((probe - (int)(threadIdx.x & 15)) & 15) == 2) ? 1 : -1;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= CF::tab_total) return;
+    const int k = t >= CF::tab_blk(0) ? 1 : 0;
+    int e = (int)(t - (k ? CF::tab_blk(0) : 0));
+    const DevBlock& B = Cd.b[k];
+    const int nch = k == 0 ? CF::NCH0 : NG, I = k == 0 ? CF::I0 : C;
+    // which table
+    const float* W;
+    int Iw, NB, which;   // which: 0 W1, 1 W1t, 2 WR, 3 WRt, 4 WL, 5 WLt
+    const int s1 = NG * nch * PAIR, s2 = NG * NG * PAIR;
+    if (e < s1) { which = 0; }
+    else if (e < 2 * s1) { which = 1; e -= s1; }
+    else { e -= 2 * s1; which = 2 + e / s2; e %= s2; }
+    const bool tr = which & 1;
+    if (which < 2) { W = B.W1; Iw = I; } else { W = which < 4 ? B.WR : B.WL; Iw = C; }
+    const bool chunked = which < 2;
+    NB = which == 0 ? nch : (which == 1 ? NG : NG);
+    const int f = e % 24, n = (e / 24) % 16, pair = e / PAIR;
+    const int a = pair / NB, b = pair % NB;
+    const int r = f / GC, cls = f % GC, c = n >> 1, s = n & 1;
+    const int sc = (c + dir * r) & 7;
+    const int g = s ? ALG::n - 2 * cls : 2 * cls;
+    // forward table [og = a][in = b]: W[8a + c][base(b) + sc]; transposed [in = a][og = b]: W[8b + sc][base(a) + c]
+    int o, cin;
+    bool ok;
+    if (!tr) {
+        const int base = chunked ? (k == 0 ? CF::chunk_base(b) : 8 * b) : 8 * b;
+        const int nv = chunked ? (k == 0 ? CF::chunk_valid(b) : (C - 8 * b < 8 ? C - 8 * b : 8)) : (C - 8 * b < 8 ? C - 8 * b : 8);
+        o = 8 * a + c; cin = base + sc; ok = o < C && sc < nv;
+    } else {
+        const int base = chunked ? (k == 0 ? CF::chunk_base(a) : 8 * a) : 8 * a;
+        const int nv = chunked ? (k == 0 ? CF::chunk_valid(a) : (C - 8 * a < 8 ? C - 8 * a : 8)) : (C - 8 * a < 8 ? C - 8 * a : 8);
+        o = 8 * b + sc; cin = base + c; ok = o < C && c < nv;
+    }
+    tabs[t] = ok ? W[((size_t)o * Iw + cin) * G + g] : 0.f;
+}
+
+// acc[j] += sum_r T[r][class(j)] * rot_r(x[j]) with the 24 weights of this lane at tp (6 x 16 bytes, global)
+template <class ALG>
+CSMPN_DEV void plw_mix(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL], const float* tp) {
+    using P = PS<ALG>;
+    constexpr int GC = P::GC, DL = P::DL;
+    f4 wv[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) wv[e] = pl_ld4(tp + 4 * e);
+    static_for<0, 8>([&](auto r) {
+        static_for<0, DL>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            constexpr int f = decltype(r)::value * GC + P::t.cls[j];
+            acc[j] = __builtin_fmaf(wv[f / 4][f % 4], pl_rot<decltype(r)::value>(x[j]), acc[j]);
+        });
+        pl_pin<0, DL>(acc);
+    });
+}
+template <class ALG>
+CSMPN_DEV void plw_mix2(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL],
+                        const float* tpa, const float* tpb) {
+    using P = PS<ALG>;
+    constexpr int GC = P::GC, DL = P::DL;
+    f4 wa[6], wb[6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) { wa[e] = pl_ld4(tpa + 4 * e); wb[e] = pl_ld4(tpb + 4 * e); }
+    static_for<0, 8>([&](auto r) {
+        static_for<0, DL>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            constexpr int f = decltype(r)::value * GC + P::t.cls[j];
+            const float t = pl_rot<decltype(r)::value>(x[j]);
+            accA[j] = __builtin_fmaf(wa[f / 4][f % 4], t, accA[j]);
+            accB[j] = __builtin_fmaf(wb[f / 4][f % 4], t, accB[j]);
+        });
+        pl_pin<0, DL>(accA);
+        pl_pin<0, DL>(accB);
+    });
+}
+
+// exchange buffer access: this wave's tensor -> [group][slot][lane]; any group's tensor at this lane position
+template <class ALG>
+CSMPN_DEV void plw_put(float* xb, int group, int lane, const float (&x)[PS<ALG>::DL]) {
+    float* p = xb + group * (PS<ALG>::DL * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < PS<ALG>::DL; ++j) p[j * 64] = x[j];
+}
+template <class ALG>
+CSMPN_DEV void plw_get(float (&x)[PS<ALG>::DL], const float* xb, int group, int lane) {
+    const float* p = xb + group * (PS<ALG>::DL * 64) + lane;
+#pragma unroll
+    for (int j = 0; j < PS<ALG>::DL; ++j) x[j] = p[j * 64];
+}
+
+// sum of one float per (row, group) over the groups; result in every wave. slot: which of the two LN buffers.
+template <class CF>
+CSMPN_DEV float plw_group_sum(float* lds, int slot, int wave, int q, float v) {
+    float* p = lds + CF::ln_off + slot * CF::NG * kPlRows;
+    p[wave * kPlRows + q] = v;          // all 16 lanes of a row hold the same value
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < CF::NG; ++g) t += p[g * kPlRows + q];
+    return t;
+}
+
+// block forward behind the MVLinear (S.y = MVLinear output without bias); mixing through the exchange buffers.
+// Barriers: every wave of the workgroup executes this function for the same tile.
+template <class ALG, class CF, int K>
+CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& ge, int wave, bool cvalid,
+                              PlState<ALG>& S, float (&out)[PS<ALG>::DL]) {
+    using P = PS<ALG>;
+    constexpr int DL = P::DL, GC = P::GC, G = ALG::G, NG = CF::NG;
+    const int c = 8 * wave + ge.c;       // channel in the (padded) layer
+    if (ge.s == 0) S.y[0] += lds[CF::p_b1(K) + c];
+    float z[DL];
+    static_for<0, GC>([&](auto k) {
+        constexpr int j0 = P::t.cstart[k], j1 = P::t.cstart[k + 1];
+        float u = 0.f;
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            u += ge.template qs<j>() * S.y[j] * S.y[j];
+        });
+        if constexpr (k == 0) {
+            if (ge.s == 0) u = S.y[0];
+        }
+        const int pg = c * G + ge.grade(k);
+        S.gate[k] = sigmoidf(lds[CF::p_sa(K) + pg] * u + lds[CF::p_sb(K) + pg]);
+        static_for<j0, j1>([&](auto jj) { z[decltype(jj)::value] = S.gate[k] * S.y[decltype(jj)::value]; });
+    });
+    CSMPN_PHASE();
+    // linear_right / linear_left over all groups
+    float L[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
+    float* xb = lds + CF::x_off(0);
+    __syncthreads();                      // the buffer's previous readers are done
+    plw_put<ALG>(xb, wave, ge.lane, z);
+    __syncthreads();
+    for (int ig = 0; ig < NG; ++ig) {
+        float zi[DL];
+        plw_get<ALG>(zi, xb, ig, ge.lane);
+        const int pair = (wave * NG + ig) * 16 + ge.n;
+        plw_mix2<ALG>(S.R, L, zi, tabs + CF::t_WR(K) + pair * 24, tabs + CF::t_WL(K) + pair * 24);
+    }
+    if (ge.s == 0) L[0] += lds[CF::p_bL(K) + c];
+    CSMPN_PHASE();
+    float r[DL];
+    static_for<0, GC>([&](auto k) {
+        constexpr int j0 = P::t.cstart[k], j1 = P::t.cstart[k + 1];
+        float qq = 0.f;
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            qq += ge.template qs<j>() * S.R[j] * S.R[j];
+        });
+        const float sg = lds[CF::p_sg(K) + c * G + ge.grade(k)];
+        const float m = sg * (smooth_abs_sqrt1(qq) - 1.0f) + 1.0f;
+        S.invden[k] = fast_rcp(m + kEps);
+        static_for<j0, j1>([&](auto jj) { r[decltype(jj)::value] = S.R[decltype(jj)::value] * S.invden[k]; });
+    });
+    CSMPN_PHASE();
+    pl_weighted_gp<ALG>(L, z, r, lds + CF::p_w(K) + c * ALG::P, ge);
+#pragma unroll
+    for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? L[j] * kInvSqrt2 : 0.f;
+    CSMPN_PHASE();
+    float qs = 0.f;
+    static_for<0, DL>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        qs += ge.template qs<j>() * S.s[j] * S.s[j];
+    });
+    qs += pl_partner(qs);
+    S.qs = qs;
+    S.nl = smooth_abs_sqrt1(qs);
+    const float part = pl_chan_sum(cvalid ? S.nl : 0.f);
+    const float tot = plw_group_sum<CF>(lds, 0, wave, ge.q, part);
+    S.invMn = fast_rcp(tot * (1.0f / float(CF::C)) + kEps);
+    const float la = lds[CF::p_la(K) + c];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) out[j] = la * S.s[j] * S.invMn;
+}
+
+// ---------------------------------------------------------------------------------
+// forward kernel: two blocks of C channels. BWD kernels: see cemlp_plw_bwd below.
+template <class ALG, class CF>
+__global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+    typedef const char __attribute__((address_space(4))) * KArgPtr;
+    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
+    const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
+    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
+    (void)C_arg; (void)io_arg;
+    using P = PS<ALG>;
+    constexpr int D = ALG::D, DL = P::DL, G = ALG::G, NG = CF::NG, C = CF::C, CP = CF::CP, ROW = CF::ROW, RS = CF::RS;
+    constexpr int MODE = CF::MODE, NA = CF::NA, NT = 64 * NG, NCH0 = CF::NCH0;
+    static_assert(CF::fwd_total * 4 <= 160 * 1024, "LDS footprint");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds = smem;
+    const int wave = threadIdx.x >> 6;
+    const PlGeo<ALG> ge(threadIdx.x & 63);
+    const bool cvalid = 8 * wave + ge.c < C;
+    const float* tabs = io.plw_tabs;
+    float* stg = lds + CF::st_off;
+    // per-channel parameters -> LDS (zero beyond C)
+    static_for<0, 2>([&](auto kk) {
+        constexpr int K = decltype(kk)::value;
+        const DevBlock& B = Cd.b[K];
+        for (int e = threadIdx.x; e < CP; e += NT) {
+            const bool ok = e < C;
+            lds[CF::p_b1(K) + e] = (ok && B.has_b1) ? B.b1[e] : 0.f;
+            lds[CF::p_bL(K) + e] = ok ? B.bL[e] : 0.f;
+            lds[CF::p_la(K) + e] = ok ? B.la[e] : 0.f;
+        }
+        for (int e = threadIdx.x; e < CP * G; e += NT) {
+            const bool ok = e < C * G;
+            lds[CF::p_sa(K) + e] = ok ? B.sa[e] : 0.f;
+            lds[CF::p_sb(K) + e] = ok ? B.sb[e] : 0.f;
+            lds[CF::p_sg(K) + e] = ok ? sigmoidf(B.an[e]) : 0.5f;
+        }
+        for (int e = threadIdx.x; e < CP * ALG::P; e += NT) lds[CF::p_w(K) + e] = e < C * ALG::P ? B.w[e] : 0.f;
+    });
+    __syncthreads();
+
+    const long ntiles = (io.rows + kPlRows - 1) / kPlRows;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row = tile * kPlRows + ge.q;
+        const bool valid = row < io.rows;
+        const long lrow = valid ? row : 0;
+        int i_dst = -1, i_src = -1, i_perm = 0;
+        float scale = 1.0f;
+        if (valid) {
+            if constexpr (MODE == MODE_EDGE) {
+                i_dst = io.seg[0].ia[row];
+                i_src = io.seg[0].ib[row];
+                if constexpr (NA > 0) i_perm = io.seg[1].ia[row];
+            } else if (io.seg[1].deg) {
+                const int dg = io.seg[1].deg[row];
+                scale = 1.0f / float(dg > 1 ? dg : 1);
+            }
+        }
+        // chunk j of the block-0 input (8 channels of one segment) at this lane's channel position
+        auto load_chunk = [&](int j, float (&x)[DL]) {
+            const int seg = j / NG, grp = j % NG;
+            const bool attr = j >= CF::NSEG * NG;
+            const int ch = attr ? ge.c : 8 * grp + ge.c;
+            const bool on = valid && ch < (attr ? NA : C);
+            const int co = (on ? ch : 0) * D;
+            if constexpr (MODE == MODE_EDGE) {
+                if (!attr) {
+                    pl_load_diff<ALG>(x, io.seg[0].a + (size_t)(valid ? i_dst : 0) * ROW + co,
+                                      io.seg[0].b + (size_t)(valid ? i_src : 0) * ROW + co, ge.s, on ? 1.0f : 0.0f);
+                } else {
+                    pl_load<ALG>(x, io.seg[1].a + (size_t)(valid ? i_perm : 0) * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                }
+            } else {
+                if (attr) pl_load<ALG>(x, io.seg[2].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                else if (seg == 0) pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * ROW + co, ge.s, on ? 1.0f : 0.0f);
+                else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
+            }
+        };
+        PlState<ALG> S;
+#pragma unroll
+        for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+        for (int j = 0; j < NCH0; ++j) {
+            float x[DL];
+            load_chunk(j, x);
+            plw_mix<ALG>(S.y, x, tabs + CF::t_W1(0) + ((wave * NCH0 + j) * 16 + ge.n) * 24);
+        }
+        float out[DL];
+        plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
+        // block-1 input: to the exchange buffer (and to HBM for the backward)
+        float* xb1 = lds + CF::x_off(1);
+        plw_put<ALG>(xb1, wave, ge.lane, out);
+        if (io.save) pl_stage<ALG>(stg + 8 * wave * D, out, ge, RS, cvalid);
+        __syncthreads();
+        if (io.save) {
+            for (int r = 0; r < kPlRows; ++r) {
+                const long rr = tile * kPlRows + r;
+                if (rr < io.rows)
+                    for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
+                        *reinterpret_cast<f4*>(io.save + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+        for (int ig = 0; ig < NG; ++ig) {
+            float xi[DL];
+            plw_get<ALG>(xi, xb1, ig, ge.lane);
+            plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
+        }
+        plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
+        if constexpr (MODE == MODE_NODE) {
+            if (io.resid) {
+                float res[DL];
+                pl_load<ALG>(res, io.resid + (size_t)lrow * ROW + (cvalid ? 8 * wave + ge.c : 0) * D, ge.s, cvalid ? 1.0f : 0.0f);
+#pragma unroll
+                for (int j = 0; j < DL; ++j) out[j] += res[j];
+            }
+        }
+        __syncthreads();                  // the staging tile's readers (save copy) are done
+        pl_stage<ALG>(stg + 8 * wave * D, out, ge, RS, cvalid);
+        __syncthreads();
+        if constexpr (MODE == MODE_EDGE) {
+            // scatter-add whole rows to agg[dst]; equal consecutive targets are summed first
+            int tg[kPlRows];
+#pragma unroll
+            for (int r = 0; r < kPlRows; ++r) tg[r] = __builtin_amdgcn_readlane(i_dst, 16 * r);
+            for (int col = threadIdx.x; col < ROW; col += NT) {
+                float acc = 0.f;
+                int cur = tg[0];
+#pragma unroll
+                for (int r = 0; r < kPlRows; ++r) {
+                    if (tg[r] != cur) {
+                        if (cur >= 0) atomicAdd(io.agg + (long)cur * ROW + col, acc);
+                        cur = tg[r];
+                        acc = 0.f;
+                    }
+                    acc += stg[r * RS + col];
+                }
+                if (cur >= 0) atomicAdd(io.agg + (long)cur * ROW + col, acc);
+            }
+        } else {
+            for (int r = 0; r < kPlRows; ++r) {
+                const long rr = tile * kPlRows + r;
+                if (rr < io.rows)
+                    for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
+                        *reinterpret_cast<f4*>(io.y + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+            }
+        }
+        __syncthreads();                  // staging tile and exchange buffers free for the next tile
+    }
+}
+
+}  // namespace csmpn

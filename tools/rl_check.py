@@ -7,7 +7,7 @@ pkg = importlib.import_module("clifford-group-equivariant-simplicial-message-pas
 from oracle import ref_path as O
 from csmpn_hip import ops
 dev = torch.device("cuda:0")
-N, E, C = int(os.environ.get("N", 10000)), int(os.environ.get("E", 100000)), 8
+N, E, C = int(os.environ.get("N", 10000)), int(os.environ.get("E", 100000)), int(os.environ.get("C", 8))
 METRIC = {"cl30": [1.0, 1.0, 1.0], "cl50": [1.0] * 5, "cl41": [1.0, 1.0, 1.0, 1.0, -1.0]}[os.environ.get("ALG", "cl30")]
 torch.manual_seed(0)
 layer = pkg.EGCL(pkg.CliffordAlgebra(tuple(METRIC)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
