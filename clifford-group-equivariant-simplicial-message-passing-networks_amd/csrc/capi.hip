@@ -596,6 +596,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             const unsigned grid = (unsigned)(tiles < kPlwMaxGroups ? tiles : kPlwMaxGroups);
             const size_t tb = cemlp_plw_table_floats_n5(mode, channels, attr) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
+            if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
             bool handled = false;
             static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_plw) fprintf(stderr, "[csmpn] plw mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
@@ -840,6 +841,9 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
     size_t ch = 0;
     for (int k = 0; k + 1 < n_blocks; ++k) ch += (size_t)blocks[k].out_features;
+    // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
+    // of d/d(block-1 input) from its block-1 launch to its block-0 launch
+    if (plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
     return ch << n;
 }
 

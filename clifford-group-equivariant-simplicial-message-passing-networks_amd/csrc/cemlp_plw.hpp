@@ -409,4 +409,472 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// backward
+
+template <int NT>
+CSMPN_DEV void plw_sum_add(float* tot, int slot, float v) {
+    float* p = tot + slot * NT;
+    *p = *p + v;
+}
+
+// block backward from d/d(out) to d/d(MVLinear output). Needs: S (recomputed forward state), z of every group in
+// exchange buffer 0 (left there by plw_block_tail). Accumulates the WR / WL gradient tiles per input group and the
+// small sums.
+template <class ALG, class CF, int K>
+CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG>& ge, int wave, bool cvalid,
+                                  const PlState<ALG>& S, const float (&gout)[PS<ALG>::DL], float (&gy)[PS<ALG>::DL],
+                                  float* tot, f4 (&accWR)[CF::NG][PS<ALG>::GC], f4 (&accWL)[CF::NG][PS<ALG>::GC]) {
+    using P = PS<ALG>;
+    using SI = PlSumIdx<ALG>;
+    constexpr int DL = P::DL, GC = P::GC, G = ALG::G, NG = CF::NG, NT = 64 * NG;
+    const int c = 8 * wave + ge.c;
+    const float la = lds[CF::p_la(K) + c];
+    float* xb0 = lds + CF::x_off(0);
+    float* xb2 = lds + CF::x_off(2);
+    // ---- MVLayerNorm backward
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < DL; ++j) dot += gout[j] * S.s[j];
+    plw_sum_add<NT>(tot, SI::la, dot * S.invMn);
+    dot += pl_partner(dot);
+    const float part = pl_chan_sum(cvalid ? -(la * dot) * S.invMn * S.invMn : 0.f);
+    const float gMn = plw_group_sum<CF>(lds, 1, wave, ge.q, part);
+    const float inl = fast_rcp(S.nl);
+    const float gqs = (gMn * (1.0f / float(CF::C))) * (0.5f * S.qs) * (inl * inl * inl);
+    float ggp[DL];
+    static_for<0, DL>([&](auto jj) {
+        constexpr int j = decltype(jj)::value;
+        const float gs = (la * gout[j]) * S.invMn + gqs * (2.0f * ge.template qs<j>()) * S.s[j];
+        ggp[j] = cvalid ? gs * kInvSqrt2 : 0.f;
+    });
+    plw_sum_add<NT>(tot, SI::bL, ggp[0]);
+    CSMPN_PHASE();
+    // ---- linear_left: d/dz and gWL
+    float gz[DL];
+#pragma unroll
+    for (int j = 0; j < DL; ++j) gz[j] = 0.f;
+    __syncthreads();
+    plw_put<ALG>(xb2, wave, ge.lane, ggp);
+    __syncthreads();
+    for (int og = 0; og < NG; ++og) {
+        float g[DL];
+        plw_get<ALG>(g, xb2, og, ge.lane);
+        plw_mix<ALG>(gz, g, tabs + CF::t_WLt(K) + ((wave * NG + og) * 16 + ge.n) * 24);
+    }
+    static_for<0, NG>([&](auto ig) {
+        float zi[DL];
+        plw_get<ALG>(zi, xb0, decltype(ig)::value, ge.lane);
+        pl_wgrad<ALG>(accWL[decltype(ig)::value], ggp, zi);
+    });
+    CSMPN_PHASE();
+    // ---- geometric product backward
+    {
+        float gwA[P::QP], gwB[P::QP];
+#pragma unroll
+        for (int q = 0; q < P::QP; ++q) { gwA[q] = 0.f; gwB[q] = 0.f; }
+        pl_weighted_gp_bwd_z<ALG>(ggp, S, lds + CF::p_w(K) + c * ALG::P, ge, gz, gwA, gwB);
+#pragma unroll
+        for (int q = 0; q < P::QP; ++q) {
+            plw_sum_add<NT>(tot, SI::wA + q, gwA[q]);
+            plw_sum_add<NT>(tot, SI::wB + q, gwB[q]);
+        }
+    }
+    CSMPN_PHASE();
+    float gr[DL];
+    pl_weighted_gp_bwd_r<ALG>(ggp, S, lds + CF::p_w(K) + c * ALG::P, ge, gr);
+    CSMPN_PHASE();
+    // ---- NormalizationLayer backward -> gR
+    float gR[DL];
+    static_for<0, GC>([&](auto k) {
+        constexpr int j0 = P::t.cstart[k], j1 = P::t.cstart[k + 1];
+        float gden = 0.f, qR = 0.f;
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            gden -= gr[j] * S.R[j];
+            qR += ge.template qs<j>() * S.R[j] * S.R[j];
+        });
+        gden *= S.invden[k] * S.invden[k];
+        const float sg = lds[CF::p_sg(K) + c * G + ge.grade(k)];
+        const float nu = smooth_abs_sqrt1(qR);
+        plw_sum_add<NT>(tot, SI::an + k, gden * (nu - 1.0f) * sg * (1.0f - sg));
+        const float inu = fast_rcp(nu);
+        const float gq = (gden * sg) * (0.5f * qR) * (inu * inu * inu);
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            gR[j] = cvalid ? gr[j] * S.invden[k] + gq * (2.0f * ge.template qs<j>()) * S.R[j] : 0.f;
+        });
+    });
+    __syncthreads();
+    plw_put<ALG>(xb2, wave, ge.lane, gR);
+    __syncthreads();
+    for (int og = 0; og < NG; ++og) {
+        float g[DL];
+        plw_get<ALG>(g, xb2, og, ge.lane);
+        plw_mix<ALG>(gz, g, tabs + CF::t_WRt(K) + ((wave * NG + og) * 16 + ge.n) * 24);
+    }
+    static_for<0, NG>([&](auto ig) {
+        float zi[DL];
+        plw_get<ALG>(zi, xb0, decltype(ig)::value, ge.lane);
+        pl_wgrad<ALG>(accWR[decltype(ig)::value], gR, zi);
+    });
+    CSMPN_PHASE();
+    // ---- MVSiLU backward -> gy
+    static_for<0, GC>([&](auto k) {
+        constexpr int j0 = P::t.cstart[k], j1 = P::t.cstart[k + 1];
+        float ggate = 0.f, u = 0.f;
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            ggate += gz[j] * S.y[j];
+            u += ge.template qs<j>() * S.y[j] * S.y[j];
+        });
+        const bool scalar_inv = k == 0 && ge.s == 0;
+        if (scalar_inv) u = S.y[0];
+        const float gpre = ggate * S.gate[k] * (1.0f - S.gate[k]);
+        plw_sum_add<NT>(tot, SI::sa + k, gpre * u);
+        plw_sum_add<NT>(tot, SI::sb + k, gpre);
+        const float gu = gpre * lds[CF::p_sa(K) + c * G + ge.grade(k)];
+        static_for<j0, j1>([&](auto jj) {
+            constexpr int j = decltype(jj)::value;
+            float v = gz[j] * S.gate[k];
+            const float quad = gu * (2.0f * ge.template qs<j>()) * S.y[j];
+            if constexpr (k == 0 && j == 0) v += scalar_inv ? gu : quad;
+            else v += quad;
+            gy[j] = cvalid ? v : 0.f;
+        });
+    });
+    plw_sum_add<NT>(tot, SI::b1, gy[0]);
+}
+
+// end of a backward launch: MFMA tile of the (og = this wave, input chunk) block -> global gradient (atomics)
+template <class ALG, class CF>
+CSMPN_DEV void plw_flush_w(float* gW, const f4 (&acc)[PS<ALG>::GC], int wave, int I, int base, int nvalid, const PlGeo<ALG>& ge) {
+    constexpr int GC = PS<ALG>::GC, G = ALG::G;
+    if (!gW) return;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = 4 * ge.q + v, o = 8 * wave + (i >> 1), so = i & 1;
+        if (so == ge.s && o < CF::C && ge.c < nvalid) {
+#pragma unroll
+            for (int k = 0; k < GC; ++k) atomicAdd(gW + ((size_t)o * I + base + ge.c) * G + ge.grade(k), acc[k][v]);
+        }
+    }
+}
+
+// BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
+// backward -> input gradients (scatter / rows). Parameter gradients of block BLK.
+template <class ALG, class CF, int BLK>
+__global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+    typedef const char __attribute__((address_space(4))) * KArgPtr;
+    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
+    const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
+    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
+    (void)C_arg; (void)io_arg;
+    using P = PS<ALG>;
+    using SI = PlSumIdx<ALG>;
+    constexpr int D = ALG::D, DL = P::DL, G = ALG::G, GC = P::GC, NG = CF::NG, C = CF::C, CP = CF::CP, ROW = CF::ROW, RS = CF::RS;
+    constexpr int MODE = CF::MODE, NA = CF::NA, NT = 64 * NG, NCH0 = CF::NCH0, NIN = BLK == 0 ? NCH0 : NG;
+    static_assert(CF::bwd_total * 4 <= 160 * 1024, "LDS footprint");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* lds = smem;
+    const int wave = threadIdx.x >> 6;
+    const PlGeo<ALG> ge(threadIdx.x & 63);
+    const bool cvalid = 8 * wave + ge.c < C;
+    const int cch = (cvalid ? 8 * wave + ge.c : 0) * D;   // this lane's channel offset inside a C-wide row
+    const float* tabs = io.plw_tabs;
+    float* stg = lds + CF::st_off;
+    float* tot = lds + CF::tot_off + threadIdx.x;
+    {
+        const DevBlock& B = Cd.b[BLK];
+        for (int e = threadIdx.x; e < CP; e += NT) {
+            const bool ok = e < C;
+            lds[CF::p_b1(BLK) + e] = (ok && B.has_b1) ? B.b1[e] : 0.f;
+            lds[CF::p_bL(BLK) + e] = ok ? B.bL[e] : 0.f;
+            lds[CF::p_la(BLK) + e] = ok ? B.la[e] : 0.f;
+        }
+        for (int e = threadIdx.x; e < CP * G; e += NT) {
+            const bool ok = e < C * G;
+            lds[CF::p_sa(BLK) + e] = ok ? B.sa[e] : 0.f;
+            lds[CF::p_sb(BLK) + e] = ok ? B.sb[e] : 0.f;
+            lds[CF::p_sg(BLK) + e] = ok ? sigmoidf(B.an[e]) : 0.5f;
+        }
+        for (int e = threadIdx.x; e < CP * ALG::P; e += NT) lds[CF::p_w(BLK) + e] = e < C * ALG::P ? B.w[e] : 0.f;
+        for (int e = threadIdx.x; e < CF::n_sums * NT; e += NT) lds[CF::tot_off + e] = 0.f;
+    }
+    __syncthreads();
+
+    f4 aW1[NIN][GC], aWR[NG][GC], aWL[NG][GC];
+#pragma unroll
+    for (int k = 0; k < GC; ++k) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) aW1[i][k] = splat(0.f);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) { aWR[i][k] = splat(0.f); aWL[i][k] = splat(0.f); }
+    }
+
+    const long ntiles = (io.rows + kPlRows - 1) / kPlRows;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row = tile * kPlRows + ge.q;
+        const bool valid = row < io.rows;
+        const long lrow = valid ? row : 0;
+        int i_dst = -1, i_src = -1, i_perm = 0;
+        float scale = 1.0f;
+        if (valid) {
+            if constexpr (MODE == MODE_EDGE) {
+                i_dst = io.seg[0].ia[row];
+                i_src = io.seg[0].ib[row];
+                if constexpr (NA > 0) i_perm = io.seg[1].ia[row];
+            } else if (io.seg[1].deg) {
+                const int dg = io.seg[1].deg[row];
+                scale = 1.0f / float(dg > 1 ? dg : 1);
+            }
+        }
+        const float von = (valid && cvalid) ? 1.0f : 0.0f;
+        float* xb1 = lds + CF::x_off(1);
+        float* xb2 = lds + CF::x_off(2);
+        if constexpr (BLK == 1) {
+            float gout[DL], in1[DL], gy[DL];
+            {
+                const long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                pl_load<ALG>(gout, io.gy + (size_t)grow * ROW + cch, ge.s, von);
+            }
+            pl_load<ALG>(in1, io.saved + (size_t)lrow * ROW + cch, ge.s, von);
+            {
+                PlState<ALG> S;
+                float unused[DL];
+#pragma unroll
+                for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+                plw_put<ALG>(xb1, wave, ge.lane, in1);
+                __syncthreads();
+                for (int ig = 0; ig < NG; ++ig) {
+                    float xi[DL];
+                    plw_get<ALG>(xi, xb1, ig, ge.lane);
+                    plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
+                }
+                plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, unused);
+                plw_block_backward<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, gout, gy, tot, aWR, aWL);
+            }
+            static_for<0, NG>([&](auto ig) {
+                float xi[DL];
+                plw_get<ALG>(xi, xb1, decltype(ig)::value, ge.lane);
+                pl_wgrad<ALG>(aW1[decltype(ig)::value], gy, xi);
+            });
+            float g1[DL];
+#pragma unroll
+            for (int j = 0; j < DL; ++j) g1[j] = 0.f;
+            __syncthreads();
+            plw_put<ALG>(xb2, wave, ge.lane, gy);
+            __syncthreads();
+            for (int og = 0; og < NG; ++og) {
+                float g[DL];
+                plw_get<ALG>(g, xb2, og, ge.lane);
+                plw_mix<ALG>(g1, g, tabs + CF::t_W1t(1) + ((wave * NG + og) * 16 + ge.n) * 24);
+            }
+            pl_stage<ALG>(stg + 8 * wave * D, g1, ge, RS, cvalid);
+            __syncthreads();
+            for (int r = 0; r < kPlRows; ++r) {
+                const long rr = tile * kPlRows + r;
+                if (rr < io.rows)
+                    for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
+                        *reinterpret_cast<f4*>(io.plw_g1 + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+            }
+            __syncthreads();
+        } else {
+            auto load_chunk = [&](int j, float (&x)[DL]) {
+                const int seg = j / NG, grp = j % NG;
+                const bool attr = j >= CF::NSEG * NG;
+                const int ch = attr ? ge.c : 8 * grp + ge.c;
+                const bool on = valid && ch < (attr ? NA : C);
+                const int co = (on ? ch : 0) * D;
+                if constexpr (MODE == MODE_EDGE) {
+                    if (!attr) {
+                        pl_load_diff<ALG>(x, io.seg[0].a + (size_t)(valid ? i_dst : 0) * ROW + co,
+                                          io.seg[0].b + (size_t)(valid ? i_src : 0) * ROW + co, ge.s, on ? 1.0f : 0.0f);
+                    } else {
+                        pl_load<ALG>(x, io.seg[1].a + (size_t)(valid ? i_perm : 0) * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                    }
+                } else {
+                    if (attr) pl_load<ALG>(x, io.seg[2].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                    else if (seg == 0) pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * ROW + co, ge.s, on ? 1.0f : 0.0f);
+                    else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
+                }
+            };
+            float g1[DL], gy0[DL];
+            pl_load<ALG>(g1, io.plw_g1 + (size_t)lrow * ROW + cch, ge.s, von);
+            {
+                PlState<ALG> S;
+                float unused[DL];
+#pragma unroll
+                for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+                for (int j = 0; j < NCH0; ++j) {
+                    float x[DL];
+                    load_chunk(j, x);
+                    plw_mix<ALG>(S.y, x, tabs + CF::t_W1(0) + ((wave * NCH0 + j) * 16 + ge.n) * 24);
+                }
+                plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, unused);
+                plw_block_backward<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, g1, gy0, tot, aWR, aWL);
+            }
+            static_for<0, NCH0>([&](auto jc) {
+                float x[DL];
+                load_chunk(decltype(jc)::value, x);
+                pl_wgrad<ALG>(aW1[decltype(jc)::value], gy0, x);
+            });
+            __syncthreads();
+            plw_put<ALG>(xb2, wave, ge.lane, gy0);
+            __syncthreads();
+            // d/d(input chunk j): wave j % NG; segment by segment through the staging tile
+            auto chunk_grad = [&](int j, float (&gx)[DL]) {
+#pragma unroll
+                for (int t = 0; t < DL; ++t) gx[t] = 0.f;
+                for (int og = 0; og < NG; ++og) {
+                    float g[DL];
+                    plw_get<ALG>(g, xb2, og, ge.lane);
+                    plw_mix<ALG>(gx, g, tabs + CF::t_W1t(0) + ((j * NG + og) * 16 + ge.n) * 24);
+                }
+            };
+            auto copy_rows = [&](float* dst, int ncol, auto row_of) {
+                for (int r = 0; r < kPlRows; ++r) {
+                    const long rr = tile * kPlRows + r;
+                    if (rr < io.rows) {
+                        float* d = dst + (size_t)row_of(r, rr) * ncol;
+                        for (int e = 4 * threadIdx.x; e < ncol; e += 4 * NT) *reinterpret_cast<f4*>(d + e) = pl_ld4(stg + r * RS + e);
+                    }
+                }
+            };
+            static_for<0, CF::NSEG>([&](auto sgc) {
+                constexpr int sg_ = decltype(sgc)::value;
+                float* dstp = io.gx[sg_];
+                if (dstp) {
+                    float gx[DL];
+                    chunk_grad(sg_ * NG + wave, gx);
+                    if constexpr (MODE == MODE_NODE) {
+                        if constexpr (sg_ == 0) {
+                            if (io.resid_bwd) {
+                                float go[DL];
+                                pl_load<ALG>(go, io.gy + (size_t)lrow * ROW + cch, ge.s, von);
+#pragma unroll
+                                for (int t = 0; t < DL; ++t) gx[t] += go[t];
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < DL; ++t) gx[t] *= scale;
+                        }
+                    }
+                    pl_stage<ALG>(stg + 8 * wave * D, gx, ge, RS, cvalid);
+                    __syncthreads();
+                    if constexpr (MODE == MODE_EDGE) {
+                        int td[kPlRows], ts[kPlRows];
+#pragma unroll
+                        for (int r = 0; r < kPlRows; ++r) {
+                            td[r] = __builtin_amdgcn_readlane(i_dst, 16 * r);
+                            ts[r] = __builtin_amdgcn_readlane(i_src, 16 * r);
+                        }
+                        for (int col = threadIdx.x; col < ROW; col += NT) {
+                            float acc = 0.f;
+                            int cur = td[0];
+#pragma unroll
+                            for (int r = 0; r < kPlRows; ++r) {
+                                const float v = stg[r * RS + col];
+                                if (td[r] != cur) {
+                                    if (cur >= 0) atomicAdd(dstp + (long)cur * ROW + col, acc);
+                                    cur = td[r];
+                                    acc = 0.f;
+                                }
+                                acc += v;
+                                if (ts[r] >= 0) atomicAdd(dstp + (long)ts[r] * ROW + col, -v);
+                            }
+                            if (cur >= 0) atomicAdd(dstp + (long)cur * ROW + col, acc);
+                        }
+                    } else {
+                        copy_rows(dstp, ROW, [&](int, long rr) { return rr; });
+                    }
+                    __syncthreads();
+                }
+            });
+            if constexpr (NA > 0) {
+                float* dstp = io.gx[CF::NSEG];
+                if (dstp) {
+                    if (wave == 0) {
+                        float gx[DL];
+                        chunk_grad(CF::NSEG * NG, gx);
+                        pl_stage<ALG>(stg, gx, ge, RS, ge.c < NA);
+                    }
+                    __syncthreads();
+                    if constexpr (MODE == MODE_EDGE) {
+                        int tp[kPlRows];
+#pragma unroll
+                        for (int r = 0; r < kPlRows; ++r) tp[r] = __builtin_amdgcn_readlane(i_perm, 16 * r);
+                        copy_rows(dstp, NA * D, [&](int r, long) { return (long)tp[r]; });
+                    } else {
+                        copy_rows(dstp, NA * D, [&](int, long rr) { return rr; });
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // ---- parameter gradients of block BLK
+    {
+        const DevBlock& B = Cd.b[BLK];
+        if constexpr (BLK == 0) {
+            static_for<0, NCH0>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                plw_flush_w<ALG, CF>(B.gW1, aW1[j], wave, CF::I0, CF::chunk_base(j), CF::chunk_valid(j), ge);
+            });
+        } else {
+            static_for<0, NG>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                plw_flush_w<ALG, CF>(B.gW1, aW1[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
+            });
+        }
+        static_for<0, NG>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            plw_flush_w<ALG, CF>(B.gWR, aWR[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
+            plw_flush_w<ALG, CF>(B.gWL, aWL[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
+        });
+        // small sums: lanes -> LDS image (the exchange buffers are free now) -> one round of global atomics
+        constexpr int i_b1 = 0, i_bL = CP, i_la = 2 * CP, i_sa = 3 * CP, i_sb = i_sa + CP * G, i_an = i_sb + CP * G,
+                      i_w = i_an + CP * G, i_tot = i_w + CP * ALG::P;
+        static_assert(i_tot <= CF::NXB * CF::XB, "image fits the exchange buffers");
+        float* img = lds + CF::x_off(0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < i_tot; e += NT) img[e] = 0.f;
+        __syncthreads();
+        const int c = 8 * wave + ge.c;
+        atomicAdd(img + i_la + c, tot[SI::la * NT]);
+        if (ge.s == 0) {
+            atomicAdd(img + i_bL + c, tot[SI::bL * NT]);
+            atomicAdd(img + i_b1 + c, tot[SI::b1 * NT]);
+        }
+#pragma unroll
+        for (int k = 0; k < GC; ++k) {
+            const int pg = c * G + ge.grade(k);
+            atomicAdd(img + i_an + pg, tot[(SI::an + k) * NT]);
+            atomicAdd(img + i_sa + pg, tot[(SI::sa + k) * NT]);
+            atomicAdd(img + i_sb + pg, tot[(SI::sb + k) * NT]);
+        }
+        static_for<0, P::QP>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            atomicAdd(img + i_w + c * ALG::P + (ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q]), tot[(SI::wA + q) * NT]);
+            atomicAdd(img + i_w + c * ALG::P + (ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q]),
+                      tot[(SI::wB + q) * NT] * (ge.s ? 1.0f : float(P::t.I2)));
+        });
+        __syncthreads();
+        auto flush = [&](float* dst, int off, int n) {
+            if (dst)
+                for (int e = threadIdx.x; e < n; e += NT) atomicAdd(dst + e, img[off + e]);
+        };
+        if (B.has_b1) flush(B.gb1, i_b1, C);
+        flush(B.gbL, i_bL, C);
+        flush(B.gla, i_la, C);
+        flush(B.gsa, i_sa, C * G);
+        flush(B.gsb, i_sb, C * G);
+        flush(B.gan, i_an, C * G);
+        flush(B.gw, i_w, C * ALG::P);
+    }
+}
+
 }  // namespace csmpn
