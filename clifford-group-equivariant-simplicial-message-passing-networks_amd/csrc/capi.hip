@@ -557,10 +557,10 @@ bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return id == ALG_N5 ? has_cemlp_pl_n5(mode, C.nblk, 8, *i0) : has_cemlp_pl_n5m(mode, C.nblk, 8, *i0);
 }
 
-// wide parity-lane kernels (cemlp_plw.hpp): Cl(5,0), two blocks of 9 .. 32 channels, EGCL edge / node programs
+// wide parity-lane kernels (cemlp_plw.hpp): Cl(5,0) / Cl(4,1), two blocks of 16 / 24 / 28 / 32 channels, EGCL edge / node programs
 bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
     static const bool off = getenv("CSMPN_NO_PLW") && atoi(getenv("CSMPN_NO_PLW"));
-    if (off || id != ALG_N5) return false;
+    if (off || (id != ALG_N5 && id != ALG_N5M)) return false;
     const DevCemlp& C = plan.C;
     if (C.nblk != 2) return false;
     const int ch = C.b[0].O;
@@ -577,9 +577,9 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     }
     if (C.b[0].I != (mode == MODE_EDGE ? ch : 2 * ch) + na) return false;
     if (io.row_store) return false;
-    const size_t tf = cemlp_plw_table_floats_n5(mode, ch, na);
+    const size_t tf = id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, ch, na) : cemlp_plw_table_floats_n5m(mode, ch, na);
     if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + 512) return false;
-    if (bwd && (!io.saved || !has_cemlp_plw_bwd_n5(mode, ch, na))) return false;
+    if (bwd && !io.saved) return false;
     *channels = ch;
     *attr = na;
     return true;
@@ -594,13 +594,15 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
             const long tiles = (io.rows + 3) / 4;          // one 4-row tile per workgroup iteration
             const unsigned grid = (unsigned)(tiles < kPlwMaxGroups ? tiles : kPlwMaxGroups);
-            const size_t tb = cemlp_plw_table_floats_n5(mode, channels, attr) * sizeof(float);
+            const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr)
+                                            : cemlp_plw_table_floats_n5m(mode, channels, attr)) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
             if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
             bool handled = false;
             static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_plw) fprintf(stderr, "[csmpn] plw mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
-            HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            if (id == ALG_N5) HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            else HIP_TRY(launch_cemlp_plw_n5m(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
             if (handled) return CSMPN_OK;
         }
     }

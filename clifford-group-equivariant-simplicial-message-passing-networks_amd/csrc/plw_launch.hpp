@@ -13,5 +13,6 @@ constexpr int kPlwMaxGroups = 256;   // one workgroup per CU
     hipError_t launch_cemlp_plw_##tag(int mode, int channels, int attr, bool bwd, unsigned grid, hipStream_t st, \
                                       const DevCemlp& C, const RowIO& io, float* tabs, bool* handled);
 CSMPN_DECLARE_PLW(n5)
+CSMPN_DECLARE_PLW(n5m)
 
 }  // namespace csmpn
