@@ -505,9 +505,10 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
 // bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
 // (never together with the row-per-lane region: different algebras). Upper bound over the entry points.
 size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
-    if (n != 5 || nblk != 2) return 0;
+    if (n != 5 || nblk < 1 || nblk > 2) return 0;
     const int ch = blocks[0].out_features;
-    if (ch <= 8 || ch > 32 || blocks[1].out_features != ch || blocks[1].in_features != ch) return 0;
+    if (ch <= 8 || ch > 32) return 0;
+    if (nblk == 2 && (blocks[1].out_features != ch || blocks[1].in_features != ch)) return 0;
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
     return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256;
 }
@@ -562,24 +563,27 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     static const bool off = getenv("CSMPN_NO_PLW") && atoi(getenv("CSMPN_NO_PLW"));
     if (off || (id != ALG_N5 && id != ALG_N5M)) return false;
     const DevCemlp& C = plan.C;
-    if (C.nblk != 2) return false;
+    if (C.nblk < 1 || C.nblk > 2) return false;
     const int ch = C.b[0].O;
-    if (ch <= 8 || ch > 32 || C.b[1].O != ch || C.b[1].I != ch || !C.b[0].w1_sub || !C.b[1].w1_sub) return false;
+    if (ch <= 8 || ch > 32 || !C.b[0].w1_sub) return false;
+    if (C.nblk == 2 && (C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub)) return false;
     int na = 0;
     if (mode == MODE_EDGE) {
         if (io.seg[0].ch != ch) return false;
         na = io.nseg > 1 ? io.seg[1].ch : 0;
+        if (C.b[0].I != ch + na) return false;
     } else if (mode == MODE_NODE) {
         if (io.seg[0].ch != ch || io.seg[1].ch != ch) return false;
         na = io.nseg > 2 ? io.seg[2].ch : 0;
+        if (C.b[0].I != 2 * ch + na) return false;
     } else {
-        return false;
+        na = C.b[0].I;                      // standalone CEMLP: its (<= 8) input channels are the one input chunk
+        if (na < 1 || na > 8 || io.nseg != 1) return false;
     }
-    if (C.b[0].I != (mode == MODE_EDGE ? ch : 2 * ch) + na) return false;
     if (io.row_store) return false;
-    const size_t tf = id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, ch, na) : cemlp_plw_table_floats_n5m(mode, ch, na);
+    const size_t tf = id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, ch, na, C.nblk) : cemlp_plw_table_floats_n5m(mode, ch, na, C.nblk);
     if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + 512) return false;
-    if (bwd && !io.saved) return false;
+    if (bwd && C.nblk > 1 && !io.saved) return false;
     *channels = ch;
     *attr = na;
     return true;
@@ -594,15 +598,15 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
             const long tiles = (io.rows + 3) / 4;          // one 4-row tile per workgroup iteration
             const unsigned grid = (unsigned)(tiles < kPlwMaxGroups ? tiles : kPlwMaxGroups);
-            const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr)
-                                            : cemlp_plw_table_floats_n5m(mode, channels, attr)) * sizeof(float);
+            const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr, plan.C.nblk)
+                                            : cemlp_plw_table_floats_n5m(mode, channels, attr, plan.C.nblk)) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
-            if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
+            if (bwd && plan.C.nblk > 1) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
             bool handled = false;
             static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_plw) fprintf(stderr, "[csmpn] plw mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
-            if (id == ALG_N5) HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
-            else HIP_TRY(launch_cemlp_plw_n5m(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            if (id == ALG_N5) HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, plan.C.nblk, bwd, grid, st, plan.C, io, tabs, &handled));
+            else HIP_TRY(launch_cemlp_plw_n5m(mode, channels, attr, plan.C.nblk, bwd, grid, st, plan.C, io, tabs, &handled));
             if (handled) return CSMPN_OK;
         }
     }
@@ -845,7 +849,7 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     for (int k = 0; k + 1 < n_blocks; ++k) ch += (size_t)blocks[k].out_features;
     // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
-    if (plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
+    if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
     return ch << n;
 }
 

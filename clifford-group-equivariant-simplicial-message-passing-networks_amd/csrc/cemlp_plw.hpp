@@ -24,17 +24,19 @@
 namespace csmpn {
 
 // compile-time description of one kernel family member
-template <class ALG, int NG_, int C_, int MODE_, int NA_>
+template <class ALG, int NG_, int C_, int MODE_, int NA_, int NBLK_ = 2>
 struct PlwCfg {
     using P = PS<ALG>;
-    static constexpr int NG = NG_, C = C_, MODE = MODE_, NA = NA_, CP = 8 * NG_;
+    static constexpr int NG = NG_, C = C_, MODE = MODE_, NA = NA_, CP = 8 * NG_, NBLK = NBLK_;
     static constexpr int D = ALG::D, DL = P::DL, GC = P::GC, G = ALG::G, NP = ALG::P, QP = P::QP, N = ALG::n;
     static constexpr int ROW = C * D;
     static_assert(C > 8 * (NG - 1) && C <= 8 * NG, "NG = ceil(C / 8)");
     static_assert(NA >= 0 && NA <= 8, "attribute channels fit one chunk");
-    static_assert(MODE == MODE_EDGE || MODE == MODE_NODE, "edge / node programs");
+    static_assert(NBLK == 1 || NBLK == 2, "one or two blocks");
+    static_assert(MODE != MODE_PLAIN || NA > 0, "MODE_PLAIN: NA = input channels (one chunk)");
     // input chunks of block 0: (first channel in the concatenated input, valid channels)
-    static constexpr int NSEG = MODE == MODE_EDGE ? 1 : 2;                  // full-width segments in front of the attributes
+    static constexpr int NSEG = MODE == MODE_EDGE ? 1 : (MODE == MODE_NODE ? 2 : 0);   // full-width segments in front of the attribute chunk
+                                                                                     // (MODE_PLAIN: the <= 8 input channels are that chunk)
     static constexpr int NCH0 = NSEG * NG + (NA > 0 ? 1 : 0);
     static constexpr int I0 = NSEG * C + NA;
     static constexpr int chunk_base(int j) { return j < NSEG * NG ? (j / NG) * C + 8 * (j % NG) : NSEG * C; }
@@ -52,7 +54,7 @@ struct PlwCfg {
     static constexpr int t_WL(int k) { return t_WRt(k) + NG * NG * PAIR; }
     static constexpr int t_WLt(int k) { return t_WL(k) + NG * NG * PAIR; }
     static constexpr int tab_blk(int k) { return (2 * NG * nch(k) + 4 * NG * NG) * PAIR; }
-    static constexpr int tab_total = tab_blk(0) + tab_blk(1);
+    static constexpr int tab_total = tab_blk(0) + (NBLK > 1 ? tab_blk(1) : 0);
     // LDS (floats)
     static constexpr int par_floats = 3 * CP + 3 * CP * G + CP * NP;
     static constexpr int p_b1(int k) { return k * par_floats; }
@@ -280,7 +282,7 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
     const float* tabs = io.plw_tabs;
     float* stg = lds + CF::st_off;
     // per-channel parameters -> LDS (zero beyond C)
-    static_for<0, 2>([&](auto kk) {
+    static_for<0, CF::NBLK>([&](auto kk) {
         constexpr int K = decltype(kk)::value;
         const DevBlock& B = Cd.b[K];
         for (int e = threadIdx.x; e < CP; e += NT) {
@@ -311,9 +313,11 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
                 i_dst = io.seg[0].ia[row];
                 i_src = io.seg[0].ib[row];
                 if constexpr (NA > 0) i_perm = io.seg[1].ia[row];
-            } else if (io.seg[1].deg) {
-                const int dg = io.seg[1].deg[row];
-                scale = 1.0f / float(dg > 1 ? dg : 1);
+            } else if constexpr (MODE == MODE_NODE) {
+                if (io.seg[1].deg) {
+                    const int dg = io.seg[1].deg[row];
+                    scale = 1.0f / float(dg > 1 ? dg : 1);
+                }
             }
         }
         // chunk j of the block-0 input (8 channels of one segment) at this lane's channel position
@@ -330,10 +334,13 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
                 } else {
                     pl_load<ALG>(x, io.seg[1].a + (size_t)(valid ? i_perm : 0) * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
                 }
-            } else {
+            } else if constexpr (MODE == MODE_NODE) {
                 if (attr) pl_load<ALG>(x, io.seg[2].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
                 else if (seg == 0) pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * ROW + co, ge.s, on ? 1.0f : 0.0f);
                 else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
+            } else {
+                (void)seg;
+                pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
             }
         };
         PlState<ALG> S;
@@ -346,27 +353,29 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
         }
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
-        // block-1 input: to the exchange buffer (and to HBM for the backward)
-        float* xb1 = lds + CF::x_off(1);
-        plw_put<ALG>(xb1, wave, ge.lane, out);
-        if (io.save) pl_stage<ALG>(stg + 8 * wave * D, out, ge, RS, cvalid);
-        __syncthreads();
-        if (io.save) {
-            for (int r = 0; r < kPlRows; ++r) {
-                const long rr = tile * kPlRows + r;
-                if (rr < io.rows)
-                    for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
-                        *reinterpret_cast<f4*>(io.save + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+        if constexpr (CF::NBLK > 1) {
+            // block-1 input: to the exchange buffer (and to HBM for the backward)
+            float* xb1 = lds + CF::x_off(1);
+            plw_put<ALG>(xb1, wave, ge.lane, out);
+            if (io.save) pl_stage<ALG>(stg + 8 * wave * D, out, ge, RS, cvalid);
+            __syncthreads();
+            if (io.save) {
+                for (int r = 0; r < kPlRows; ++r) {
+                    const long rr = tile * kPlRows + r;
+                    if (rr < io.rows)
+                        for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
+                            *reinterpret_cast<f4*>(io.save + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+                }
             }
-        }
 #pragma unroll
-        for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-        for (int ig = 0; ig < NG; ++ig) {
-            float xi[DL];
-            plw_get<ALG>(xi, xb1, ig, ge.lane);
-            plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
+            for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+            for (int ig = 0; ig < NG; ++ig) {
+                float xi[DL];
+                plw_get<ALG>(xi, xb1, ig, ge.lane);
+                plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
+            }
+            plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
         }
-        plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
         if constexpr (MODE == MODE_NODE) {
             if (io.resid) {
                 float res[DL];
@@ -626,9 +635,11 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                 i_dst = io.seg[0].ia[row];
                 i_src = io.seg[0].ib[row];
                 if constexpr (NA > 0) i_perm = io.seg[1].ia[row];
-            } else if (io.seg[1].deg) {
-                const int dg = io.seg[1].deg[row];
-                scale = 1.0f / float(dg > 1 ? dg : 1);
+            } else if constexpr (MODE == MODE_NODE) {
+                if (io.seg[1].deg) {
+                    const int dg = io.seg[1].deg[row];
+                    scale = 1.0f / float(dg > 1 ? dg : 1);
+                }
             }
         }
         const float von = (valid && cvalid) ? 1.0f : 0.0f;
@@ -695,14 +706,22 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                     } else {
                         pl_load<ALG>(x, io.seg[1].a + (size_t)(valid ? i_perm : 0) * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
                     }
-                } else {
+                } else if constexpr (MODE == MODE_NODE) {
                     if (attr) pl_load<ALG>(x, io.seg[2].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
                     else if (seg == 0) pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * ROW + co, ge.s, on ? 1.0f : 0.0f);
                     else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
+                } else {
+                    (void)seg;
+                    pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
                 }
             };
             float g1[DL], gy0[DL];
-            pl_load<ALG>(g1, io.plw_g1 + (size_t)lrow * ROW + cch, ge.s, von);
+            if constexpr (CF::NBLK > 1) {
+                pl_load<ALG>(g1, io.plw_g1 + (size_t)lrow * ROW + cch, ge.s, von);
+            } else {   // single block: d/d(out) comes from the caller
+                const long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                pl_load<ALG>(g1, io.gy + (size_t)grow * ROW + cch, ge.s, von);
+            }
             {
                 PlState<ALG> S;
                 float unused[DL];
