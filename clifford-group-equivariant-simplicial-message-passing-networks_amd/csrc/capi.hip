@@ -504,13 +504,18 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
 
 // bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
 // (never together with the row-per-lane region: different algebras). Upper bound over the entry points.
+// ... and of the backward's partial buffer: one slice of weight-gradient MFMA tiles per workgroup (upper bound)
+size_t plw_part_bytes(int ch) {
+    const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
+    return (nch0 + 2 * NG) * 12 * 64 * NG * sizeof(float) * kPlwMaxGroups + 256;
+}
 size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 5 || nblk < 1 || nblk > 2) return 0;
     const int ch = blocks[0].out_features;
     if (ch <= 8 || ch > 32) return 0;
     if (nblk == 2 && (blocks[1].out_features != ch || blocks[1].in_features != ch)) return 0;
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
-    return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256;
+    return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256 + plw_part_bytes(ch);
 }
 
 // Row-per-lane kernels (cemlp_rl.hpp): every block 8 channels wide, MVLinear with per-grade
@@ -582,7 +587,7 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     }
     if (io.row_store) return false;
     const size_t tf = id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, ch, na, C.nblk) : cemlp_plw_table_floats_n5m(mode, ch, na, C.nblk);
-    if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + 512) return false;
+    if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + plw_part_bytes(ch) + 1024) return false;
     if (bwd && C.nblk > 1 && !io.saved) return false;
     *channels = ch;
     *attr = na;
@@ -601,6 +606,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr, plan.C.nblk)
                                             : cemlp_plw_table_floats_n5m(mode, channels, attr, plan.C.nblk)) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
+            io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - plw_part_bytes(channels));
             if (bwd && plan.C.nblk > 1) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
             bool handled = false;
             static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;

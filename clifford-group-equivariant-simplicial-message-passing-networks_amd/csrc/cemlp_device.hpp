@@ -123,6 +123,7 @@ struct RowIO {
     int pad3_;
     const float* plw_tabs;  // wide parity-lane kernels (cemlp_plw.hpp): rotation tables packed into the workspace
     float* plw_g1;          // ... backward: d/d(block-1 input) rows handed from the block-1 launch to the block-0 launch
+    float* plw_part;        // ... backward: one slice of weight-gradient tiles per workgroup (added by plw_reduce_kernel)
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

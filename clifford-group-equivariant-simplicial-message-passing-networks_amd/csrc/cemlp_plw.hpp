@@ -556,19 +556,55 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     plw_sum_add<NT>(tot, SI::b1, gy[0]);
 }
 
-// end of a backward launch: MFMA tile of the (og = this wave, input chunk) block -> global gradient (atomics)
-template <class ALG, class CF>
-CSMPN_DEV void plw_flush_w(float* gW, const f4 (&acc)[PS<ALG>::GC], int wave, int I, int base, int nvalid, const PlGeo<ALG>& ge) {
-    constexpr int GC = PS<ALG>::GC, G = ALG::G;
+// end of a backward launch: the workgroup's MFMA tiles -> its slice of the partial buffer (plain coalesced stores);
+// plw_reduce_kernel adds the slices in a fixed order (256 workgroups adding 19 k addresses each with atomics cost
+// ~175 us per launch, more than the tile work of the small convex-hulls batches).
+// Slice layout: [tile slot][thread], slot = ((table * MAXIN + input group) * GC + class) * 4 + v; tables: 0 W1, 1 WR, 2 WL.
+template <class CF, int BLK>
+struct PlwPart {
+    static constexpr int NIN = BLK == 0 ? CF::NCH0 : CF::NG;
+    static constexpr int GC = CF::GC, NG = CF::NG, NT = 64 * CF::NG;
+    static constexpr int n_tiles = NIN + 2 * NG;                 // (W1: NIN input groups) + (WR, WL: NG each)
+    static constexpr int slots = n_tiles * GC * 4;
+    static constexpr int slice = slots * NT;                     // floats per workgroup
+    static constexpr int tile_of(int table, int ig) { return table == 0 ? ig : (table == 1 ? NIN + ig : NIN + NG + ig); }
+};
+template <class ALG, class CF, int BLK>
+CSMPN_DEV void plw_store_tile(float* slice, int tile_idx, const f4 (&acc)[PS<ALG>::GC], int tid) {
+    constexpr int GC = PS<ALG>::GC, NT = 64 * CF::NG;
+#pragma unroll
+    for (int k = 0; k < GC; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) slice[((tile_idx * GC + k) * 4 + v) * NT + tid] = acc[k][v];
+}
+// grads += sum over the workgroups' slices; one thread per (slot, thread position): a single writer per gradient
+// element, fixed summation order
+template <class ALG, class CF, int BLK>
+__global__ void plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngroups) {
+    using PP = PlwPart<CF, BLK>;
+    constexpr int GC = CF::GC, NG = CF::NG, NT = PP::NT, G = ALG::G, C = CF::C;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= PP::slice) return;
+    const int tid = (int)(t % NT), slot = (int)(t / NT);
+    const int v = slot & 3, k = (slot >> 2) % GC, tile_idx = (slot >> 2) / GC;
+    // which matrix / input group
+    int table, ig;
+    if (tile_idx < PP::NIN) { table = 0; ig = tile_idx; }
+    else if (tile_idx < PP::NIN + NG) { table = 1; ig = tile_idx - PP::NIN; }
+    else { table = 2; ig = tile_idx - PP::NIN - NG; }
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, n = lane & 15, c = n >> 1, s = n & 1;
+    const int i = 4 * q + v, o = 8 * wave + (i >> 1), so = i & 1;
+    int base, nvalid, I;
+    if (table == 0 && BLK == 0) { base = CF::chunk_base(ig); nvalid = CF::chunk_valid(ig); I = CF::I0; }
+    else { base = 8 * ig; nvalid = C - 8 * ig < 8 ? C - 8 * ig : 8; I = C; }
+    if (so != s || o >= C || c >= nvalid) return;
+    const DevBlock& B = Cd.b[BLK];
+    float* gW = table == 0 ? B.gW1 : (table == 1 ? B.gWR : B.gWL);
     if (!gW) return;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int i = 4 * ge.q + v, o = 8 * wave + (i >> 1), so = i & 1;
-        if (so == ge.s && o < CF::C && ge.c < nvalid) {
-#pragma unroll
-            for (int k = 0; k < GC; ++k) atomicAdd(gW + ((size_t)o * I + base + ge.c) * G + ge.grade(k), acc[k][v]);
-        }
-    }
+    float sum = 0.f;
+    for (int g = 0; g < ngroups; ++g) sum += part[(size_t)g * PP::slice + t];
+    const int grade = s ? ALG::n - 2 * k : 2 * k;
+    gW[((size_t)o * I + base + c) * G + grade] += sum;
 }
 
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
@@ -838,22 +874,17 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
     // ---- parameter gradients of block BLK
     {
         const DevBlock& B = Cd.b[BLK];
-        if constexpr (BLK == 0) {
-            static_for<0, NCH0>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                plw_flush_w<ALG, CF>(B.gW1, aW1[j], wave, CF::I0, CF::chunk_base(j), CF::chunk_valid(j), ge);
+        {
+            using PP = PlwPart<CF, BLK>;
+            float* slice = io.plw_part + (size_t)blockIdx.x * PP::slice;
+            static_for<0, NIN>([&](auto jc) {
+                plw_store_tile<ALG, CF, BLK>(slice, PP::tile_of(0, decltype(jc)::value), aW1[decltype(jc)::value], threadIdx.x);
             });
-        } else {
             static_for<0, NG>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                plw_flush_w<ALG, CF>(B.gW1, aW1[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
+                plw_store_tile<ALG, CF, BLK>(slice, PP::tile_of(1, decltype(jc)::value), aWR[decltype(jc)::value], threadIdx.x);
+                plw_store_tile<ALG, CF, BLK>(slice, PP::tile_of(2, decltype(jc)::value), aWL[decltype(jc)::value], threadIdx.x);
             });
         }
-        static_for<0, NG>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            plw_flush_w<ALG, CF>(B.gWR, aWR[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
-            plw_flush_w<ALG, CF>(B.gWL, aWL[j], wave, C, 8 * j, (C - 8 * j < 8 ? C - 8 * j : 8), ge);
-        });
         // small sums: lanes -> LDS image (the exchange buffers are free now) -> one round of global atomics
         constexpr int i_b1 = 0, i_bL = CP, i_la = 2 * CP, i_sa = 3 * CP, i_sb = i_sa + CP * G, i_an = i_sb + CP * G,
                       i_w = i_an + CP * G, i_tot = i_w + CP * ALG::P;
