@@ -733,9 +733,15 @@ __global__ void mvlinear_bwd_x_kernel(const MvLinDesc P) {
 // A workgroup takes a slab of rows; thread t owns weight elements t, t + 256, ... and walks the slab
 // (x / gy rows of the slab are L1/L2 hits after the first touch); one atomic per element and slab.
 constexpr int kMvLinSlab = 64;
-__global__ void mvlinear_bwd_w_kernel(const MvLinDesc P) {
-    const long r0 = (long)blockIdx.x * kMvLinSlab;
-    const long r1 = r0 + kMvLinSlab < P.rows ? r0 + kMvLinSlab : P.rows;
+// rows per workgroup: 64 for large inputs, fewer for small ones (a thread walks its slab serially: with 64 rows the
+// 128-vertex embedding of a convex-hulls batch took 260 us in two workgroups)
+inline int mvlinear_slab(long rows) {
+    long s = rows / 512;
+    return (int)(s < 4 ? 4 : (s > kMvLinSlab ? kMvLinSlab : s));
+}
+__global__ void mvlinear_bwd_w_kernel(const MvLinDesc P, int slab) {
+    const long r0 = (long)blockIdx.x * slab;
+    const long r1 = r0 + slab < P.rows ? r0 + slab : P.rows;
     const int ws = P.sub ? P.G : 1;
     const int nw = P.O * P.I * ws;
     for (int e = threadIdx.x; e < nw + P.O; e += blockDim.x) {
@@ -956,8 +962,9 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
                            (hipStream_t)stream, P);
     }
     if (g_weight || g_bias) {   // the bias gradient comes from the same kernel: a frozen weight must not silence it
-        const unsigned grid = (unsigned)((rows + kMvLinSlab - 1) / kMvLinSlab);
-        hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P);
+        const int slab = mvlinear_slab(rows);
+        const unsigned grid = (unsigned)((rows + slab - 1) / slab);
+        hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P, slab);
     }
     HIP_TRY(hipGetLastError());
     return CSMPN_OK;

@@ -580,14 +580,16 @@ CSMPN_DEV void plw_store_tile(float* slice, int tile_idx, const f4 (&acc)[PS<ALG
 // grads += sum over the workgroups' slices; one thread per (slot, thread position): a single writer per gradient
 // element, fixed summation order
 template <class ALG, class CF, int BLK>
-__global__ void plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngroups) {
+__global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngroups) {
     using PP = PlwPart<CF, BLK>;
     constexpr int GC = CF::GC, NG = CF::NG, NT = PP::NT, G = ALG::G, C = CF::C;
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= PP::slice) return;
+    // 64 slice positions per workgroup x 4 interleaved group subsets (independent loads in flight), combined in LDS
+    __shared__ float red[4][64];
+    const int sub = threadIdx.x >> 6;
+    const long t = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool in = t < PP::slice;
     const int tid = (int)(t % NT), slot = (int)(t / NT);
     const int v = slot & 3, k = (slot >> 2) % GC, tile_idx = (slot >> 2) / GC;
-    // which matrix / input group
     int table, ig;
     if (tile_idx < PP::NIN) { table = 0; ig = tile_idx; }
     else if (tile_idx < PP::NIN + NG) { table = 1; ig = tile_idx - PP::NIN; }
@@ -597,14 +599,28 @@ __global__ void plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngro
     int base, nvalid, I;
     if (table == 0 && BLK == 0) { base = CF::chunk_base(ig); nvalid = CF::chunk_valid(ig); I = CF::I0; }
     else { base = 8 * ig; nvalid = C - 8 * ig < 8 ? C - 8 * ig : 8; I = C; }
-    if (so != s || o >= C || c >= nvalid) return;
     const DevBlock& B = Cd.b[BLK];
     float* gW = table == 0 ? B.gW1 : (table == 1 ? B.gWR : B.gWL);
-    if (!gW) return;
-    float sum = 0.f;
-    for (int g = 0; g < ngroups; ++g) sum += part[(size_t)g * PP::slice + t];
-    const int grade = s ? ALG::n - 2 * k : 2 * k;
-    gW[((size_t)o * I + base + c) * G + grade] += sum;
+    const bool live = in && so == s && o < C && c < nvalid && gW != nullptr;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (live) {
+        const float* p = part + t;
+        int g = sub;
+        for (; g + 12 < ngroups; g += 16) {
+            s0 += p[(size_t)g * PP::slice];
+            s1 += p[(size_t)(g + 4) * PP::slice];
+            s2 += p[(size_t)(g + 8) * PP::slice];
+            s3 += p[(size_t)(g + 12) * PP::slice];
+        }
+        for (; g < ngroups; g += 4) s0 += p[(size_t)g * PP::slice];
+    }
+    red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sub == 0 && live) {
+        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int grade = s ? ALG::n - 2 * k : 2 * k;
+        gW[((size_t)o * I + base + c) * G + grade] += sum;
+    }
 }
 
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
