@@ -602,7 +602,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         int channels = 0, attr = 0;
         if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
             const long tiles = (io.rows + 3) / 4;          // one 4-row tile per workgroup iteration
-            const unsigned grid = (unsigned)(tiles < kPlwMaxGroups ? tiles : kPlwMaxGroups);
+            const long cap_plw = bwd ? kPlwMaxGroups : 2 * kPlwMaxGroups;   // forward: two workgroups per CU where LDS allows
+            const unsigned grid = (unsigned)(tiles < cap_plw ? tiles : cap_plw);
             const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr, plan.C.nblk)
                                             : cemlp_plw_table_floats_n5m(mode, channels, attr, plan.C.nblk)) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));

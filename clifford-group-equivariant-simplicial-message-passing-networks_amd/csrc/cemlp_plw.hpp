@@ -65,15 +65,17 @@ struct PlwCfg {
     static constexpr int p_sg(int k) { return p_sb(k) + CP * G; }
     static constexpr int p_w(int k) { return p_sg(k) + CP * G; }
     static constexpr int store_total = 2 * par_floats;
-    static constexpr int XB = NG * DL * 64;                 // one exchange buffer [group][slot][lane]
-    static constexpr int x_off(int b) { return store_total + b * XB; }
-    static constexpr int NXB = 3;
-    static constexpr int ln_off = x_off(NXB);               // [2][NG][4 rows]
+    // layout: parameters | LayerNorm exchange | staging tile | exchange buffers 0, 1 (| 2 | running sums: backward)
     static constexpr int RS = ROW + 4;
+    static constexpr int ln_off = store_total;              // [2][NG][4 rows]
     static constexpr int st_off = ln_off + 2 * NG * kPlRows + 8;   // staging tile [4 rows][ROW + 4]
-    static constexpr int fwd_total = st_off + kPlRows * RS;
+    static constexpr int XB = NG * DL * 64;                 // one exchange buffer [group][slot][lane]
+    static constexpr int x_base = (st_off + kPlRows * RS + 3) & ~3;
+    static constexpr int x_off(int b) { return x_base + b * XB; }
+    static constexpr int NXB = 3;
+    static constexpr int fwd_total = x_off(2);              // the forward uses buffers 0 and 1: two workgroups per CU
     static constexpr int n_sums = 3 + 3 * GC + 2 * QP;
-    static constexpr int tot_off = fwd_total;               // backward: lane-private running sums [slot][thread]
+    static constexpr int tot_off = x_off(NXB);              // backward: lane-private running sums [slot][thread]
     static constexpr int bwd_total = tot_off + n_sums * 64 * NG;
 };
 
@@ -121,14 +123,16 @@ __global__ void plw_pack_kernel(const DevCemlp Cd, float* tabs) {
     tabs[t] = ok ? W[((size_t)o * Iw + cin) * G + g] : 0.f;
 }
 
-// acc[j] += sum_r T[r][class(j)] * rot_r(x[j]) with the 24 weights of this lane at tp (6 x 16 bytes, global)
-template <class ALG>
-CSMPN_DEV void plw_mix(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL], const float* tp) {
-    using P = PS<ALG>;
-    constexpr int GC = P::GC, DL = P::DL;
-    f4 wv[6];
+// the 24 weights of this lane for one (output group, input group) block: 6 x 16 bytes from the packed tables (L2)
+CSMPN_DEV void plw_ldw(f4 (&wv)[6], const float* tp) {
 #pragma unroll
     for (int e = 0; e < 6; ++e) wv[e] = pl_ld4(tp + 4 * e);
+}
+// acc[j] += sum_r T[r][class(j)] * rot_r(x[j])
+template <class ALG>
+CSMPN_DEV void plw_mix_w(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL], const f4 (&wv)[6]) {
+    using P = PS<ALG>;
+    constexpr int GC = P::GC, DL = P::DL;
     static_for<0, 8>([&](auto r) {
         static_for<0, DL>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -139,13 +143,10 @@ CSMPN_DEV void plw_mix(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL],
     });
 }
 template <class ALG>
-CSMPN_DEV void plw_mix2(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL],
-                        const float* tpa, const float* tpb) {
+CSMPN_DEV void plw_mix2_w(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL],
+                          const f4 (&wa)[6], const f4 (&wb)[6]) {
     using P = PS<ALG>;
     constexpr int GC = P::GC, DL = P::DL;
-    f4 wa[6], wb[6];
-#pragma unroll
-    for (int e = 0; e < 6; ++e) { wa[e] = pl_ld4(tpa + 4 * e); wb[e] = pl_ld4(tpb + 4 * e); }
     static_for<0, 8>([&](auto r) {
         static_for<0, DL>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -157,6 +158,22 @@ CSMPN_DEV void plw_mix2(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL], 
         pl_pin<0, DL>(accA);
         pl_pin<0, DL>(accB);
     });
+}
+// sum over `count` blocks whose tables are `stride` floats apart, the next block's weights in flight while the
+// current one is computed; operand(i, x) delivers the i-th input group
+template <class ALG, class F>
+CSMPN_DEV void plw_mix_loop(float (&acc)[PS<ALG>::DL], const float* tp0, int stride, int count, F&& operand) {
+    f4 wn[6];
+    plw_ldw(wn, tp0);
+    for (int i = 0; i < count; ++i) {
+        f4 wv[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) wv[e] = wn[e];
+        if (i + 1 < count) plw_ldw(wn, tp0 + (size_t)(i + 1) * stride);
+        float x[PS<ALG>::DL];
+        operand(i, x);
+        plw_mix_w<ALG>(acc, x, wv);
+    }
 }
 
 // exchange buffer access: this wave's tensor -> [group][slot][lane]; any group's tensor at this lane position
@@ -218,11 +235,24 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
     __syncthreads();                      // the buffer's previous readers are done
     plw_put<ALG>(xb, wave, ge.lane, z);
     __syncthreads();
-    for (int ig = 0; ig < NG; ++ig) {
-        float zi[DL];
-        plw_get<ALG>(zi, xb, ig, ge.lane);
-        const int pair = (wave * NG + ig) * 16 + ge.n;
-        plw_mix2<ALG>(S.R, L, zi, tabs + CF::t_WR(K) + pair * 24, tabs + CF::t_WL(K) + pair * 24);
+    {
+        const float* tr = tabs + CF::t_WR(K) + (wave * NG * 16 + ge.n) * 24;
+        const float* tl = tabs + CF::t_WL(K) + (wave * NG * 16 + ge.n) * 24;
+        f4 ran[6], lan[6];
+        plw_ldw(ran, tr);
+        plw_ldw(lan, tl);
+        for (int ig = 0; ig < NG; ++ig) {
+            f4 ra[6], la_[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) { ra[e] = ran[e]; la_[e] = lan[e]; }
+            if (ig + 1 < NG) {
+                plw_ldw(ran, tr + (ig + 1) * CF::PAIR);
+                plw_ldw(lan, tl + (ig + 1) * CF::PAIR);
+            }
+            float zi[DL];
+            plw_get<ALG>(zi, xb, ig, ge.lane);
+            plw_mix2_w<ALG>(S.R, L, zi, ra, la_);
+        }
     }
     if (ge.s == 0) L[0] += lds[CF::p_bL(K) + c];
     CSMPN_PHASE();
@@ -263,7 +293,7 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
 // ---------------------------------------------------------------------------------
 // forward kernel: two blocks of C channels. BWD kernels: see cemlp_plw_bwd below.
 template <class ALG, class CF>
-__global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 2 : 1) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
@@ -346,11 +376,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
         PlState<ALG> S;
 #pragma unroll
         for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-        for (int j = 0; j < NCH0; ++j) {
-            float x[DL];
-            load_chunk(j, x);
-            plw_mix<ALG>(S.y, x, tabs + CF::t_W1(0) + ((wave * NCH0 + j) * 16 + ge.n) * 24);
-        }
+        plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
+                          [&](int j, float (&x)[DL]) { load_chunk(j, x); });
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
         if constexpr (CF::NBLK > 1) {
@@ -369,11 +396,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_fwd_kernel(const Dev
             }
 #pragma unroll
             for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-            for (int ig = 0; ig < NG; ++ig) {
-                float xi[DL];
-                plw_get<ALG>(xi, xb1, ig, ge.lane);
-                plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
-            }
+            plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                              [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
             plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
         }
         if constexpr (MODE == MODE_NODE) {
@@ -467,11 +491,8 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     __syncthreads();
     plw_put<ALG>(xb2, wave, ge.lane, ggp);
     __syncthreads();
-    for (int og = 0; og < NG; ++og) {
-        float g[DL];
-        plw_get<ALG>(g, xb2, og, ge.lane);
-        plw_mix<ALG>(gz, g, tabs + CF::t_WLt(K) + ((wave * NG + og) * 16 + ge.n) * 24);
-    }
+    plw_mix_loop<ALG>(gz, tabs + CF::t_WLt(K) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                      [&](int og, float (&g)[DL]) { plw_get<ALG>(g, xb2, og, ge.lane); });
     static_for<0, NG>([&](auto ig) {
         float zi[DL];
         plw_get<ALG>(zi, xb0, decltype(ig)::value, ge.lane);
@@ -518,11 +539,8 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     __syncthreads();
     plw_put<ALG>(xb2, wave, ge.lane, gR);
     __syncthreads();
-    for (int og = 0; og < NG; ++og) {
-        float g[DL];
-        plw_get<ALG>(g, xb2, og, ge.lane);
-        plw_mix<ALG>(gz, g, tabs + CF::t_WRt(K) + ((wave * NG + og) * 16 + ge.n) * 24);
-    }
+    plw_mix_loop<ALG>(gz, tabs + CF::t_WRt(K) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                      [&](int og, float (&g)[DL]) { plw_get<ALG>(g, xb2, og, ge.lane); });
     static_for<0, NG>([&](auto ig) {
         float zi[DL];
         plw_get<ALG>(zi, xb0, decltype(ig)::value, ge.lane);
@@ -711,11 +729,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                 plw_put<ALG>(xb1, wave, ge.lane, in1);
                 __syncthreads();
-                for (int ig = 0; ig < NG; ++ig) {
-                    float xi[DL];
-                    plw_get<ALG>(xi, xb1, ig, ge.lane);
-                    plw_mix<ALG>(S.y, xi, tabs + CF::t_W1(1) + ((wave * NG + ig) * 16 + ge.n) * 24);
-                }
+                plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                                  [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
                 plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, unused);
                 plw_block_backward<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, gout, gy, tot, aWR, aWL);
             }
@@ -730,11 +745,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
             __syncthreads();
             plw_put<ALG>(xb2, wave, ge.lane, gy);
             __syncthreads();
-            for (int og = 0; og < NG; ++og) {
-                float g[DL];
-                plw_get<ALG>(g, xb2, og, ge.lane);
-                plw_mix<ALG>(g1, g, tabs + CF::t_W1t(1) + ((wave * NG + og) * 16 + ge.n) * 24);
-            }
+            plw_mix_loop<ALG>(g1, tabs + CF::t_W1t(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                              [&](int og, float (&g)[DL]) { plw_get<ALG>(g, xb2, og, ge.lane); });
             pl_stage<ALG>(stg + 8 * wave * D, g1, ge, RS, cvalid);
             __syncthreads();
             for (int r = 0; r < kPlRows; ++r) {
@@ -779,11 +791,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                 float unused[DL];
 #pragma unroll
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-                for (int j = 0; j < NCH0; ++j) {
-                    float x[DL];
-                    load_chunk(j, x);
-                    plw_mix<ALG>(S.y, x, tabs + CF::t_W1(0) + ((wave * NCH0 + j) * 16 + ge.n) * 24);
-                }
+                plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
+                                  [&](int j, float (&x)[DL]) { load_chunk(j, x); });
                 plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, unused);
                 plw_block_backward<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, g1, gy0, tot, aWR, aWL);
             }
@@ -799,11 +808,8 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
             auto chunk_grad = [&](int j, float (&gx)[DL]) {
 #pragma unroll
                 for (int t = 0; t < DL; ++t) gx[t] = 0.f;
-                for (int og = 0; og < NG; ++og) {
-                    float g[DL];
-                    plw_get<ALG>(g, xb2, og, ge.lane);
-                    plw_mix<ALG>(gx, g, tabs + CF::t_W1t(0) + ((j * NG + og) * 16 + ge.n) * 24);
-                }
+                plw_mix_loop<ALG>(gx, tabs + CF::t_W1t(0) + (j * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                                  [&](int og, float (&g)[DL]) { plw_get<ALG>(g, xb2, og, ge.lane); });
             };
             auto copy_rows = [&](float* dst, int ncol, auto row_of) {
                 for (int r = 0; r < kPlRows; ++r) {
