@@ -334,8 +334,46 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_sc
 @pytest.mark.parametrize("N,E,aggr,residual", [(2, 1, "mean", True), (5, 3, "sum", True), (37, 101, "mean", False),
                                                (64, 258, "sum", True), (130, 1027, "mean", True)])
 def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
+    # Cl(4,1): the node model's gradients amplify the rounding noise of the aggregate (float atomics: the summation
+    # order of `agg` takes one of a few values per run) by ~1e2 even on these tamed inputs - measured: the same
+    # tensors land at 1.7x or 11x the reference's own float32 error depending on that order, with the node kernels
+    # themselves bit-reproducible for a fixed aggregate (test_wide_kernels_reproducible_for_fixed_inputs). Factor 20.
     _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=N + E, residual=residual,
-                      neg_scale=0.02 if min(metric) < 0 else None, attr_grad=True)
+                      neg_scale=0.02 if min(metric) < 0 else None, attr_grad=True,
+                      slack=20.0 if min(metric) < 0 else None)
+
+
+def test_wide_kernels_reproducible_for_fixed_inputs(pkg):
+    """The wide parity-lane node / edge stages on fixed inputs: outputs, every data gradient and the dense weight
+    gradients (per-workgroup slices + fixed-order reduction) are bit-identical from run to run - no race between the
+    waves of a workgroup, no dependence on scheduling. (The per-channel parameter sums go through atomics and may
+    differ in the last bits.)"""
+    from csmpn_hip import ops
+    N, E, C = 130, 1027, 32
+    metric = [1.0, 1.0, 1.0, 1.0, -1.0]
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra(tuple(metric)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
+    h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(O.Algebra(metric), N, E, C, seed=N + E))
+    be, spec = ops.HipBackend, layer.spec()
+    csr = ops.get_csr(ei, N)
+    pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+    gout = torch.randn(N, C, 32, device=dev())
+    agg, st_e = be.edge_forward(spec, csr, h, ea, pe)
+    agg = agg.clone()
+
+    def run():
+        out, st_n = be.node_forward(spec, csr.deg, h, agg, na, pn)
+        gh, g_agg, g_na, gn = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, True, st_n)
+        g_ea, ge = be.edge_backward(spec, csr, h, ea, pe, g_agg, torch.zeros_like(gh), True, st_e)
+        torch.cuda.synchronize()
+        dense = [v.clone() for v in list(gn) + list(ge) if v is not None and v.dim() == 3 and v.shape[0] == C]   # W1, WR, WL of every block
+        return [out, gh, g_agg, g_na, g_ea] + dense
+
+    ref = run()
+    assert len(ref) == 5 + 12
+    for _ in range(3):
+        for i, (a, b) in enumerate(zip(run(), ref)):
+            assert torch.equal(a, b), f"tensor {i} differs between two runs on identical inputs"
 
 
 @pytest.mark.parametrize("metric,C,hidden,aggr", [
