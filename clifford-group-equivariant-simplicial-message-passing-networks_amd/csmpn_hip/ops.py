@@ -55,6 +55,33 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+_FUSED_GRAD_ACCUM = False
+
+
+def set_fused_grad_accumulation(flag: bool):
+    """Opt-in: parameter gradients are added by the kernels straight into the existing `p.grad` tensors (the kernels
+    accumulate anyway) and the autograd functions return None for the parameters, instead of handing views of a flat
+    buffer to autograd's AccumulateGrad - one elementwise kernel per parameter tensor less (the convex-hulls model has
+    ~150 of them per step). Needs `optimizer.zero_grad(set_to_none=False)`; falls back to the flat buffer whenever a
+    parameter has no (contiguous float32, same-device) .grad yet. Parameter hooks (e.g. DistributedDataParallel's) do
+    not see gradients delivered this way: leave it off under DDP."""
+    global _FUSED_GRAD_ACCUM
+    _FUSED_GRAD_ACCUM = bool(flag)
+
+
+def _fusable(params, device) -> bool:
+    if not _FUSED_GRAD_ACCUM:
+        return False
+    for p in params:
+        if p is None:
+            continue
+        g = p.grad
+        if g is None or not p.requires_grad or g.dtype != torch.float32 or g.device != device or not g.is_contiguous() \
+                or g.shape != p.shape:
+            return False
+    return True
+
+
 class CemlpBinding:
     """ctypes view of one CEMLP's parameters, cached across calls.
 
@@ -130,12 +157,20 @@ class CemlpBinding:
                     total += (p.numel() + 3) // 4 * 4
             self._grad_layout = (offs, total)
 
-    def new_grads(self, params: Sequence[Optional[torch.Tensor]], device, flat=None):
+    def new_grads(self, params: Sequence[Optional[torch.Tensor]], device, flat=None, fused_into=None):
         """One zeroed flat buffer for all parameter gradients (a single memset; or the caller's
         already zeroed `flat` of grad_floats() elements); returns (flat, views) with views[i]
         shaped like params[i]."""
         self._layout(params)
         offs, total = self._grad_layout
+        if fused_into is not None:
+            # the kernels add into the parameters' own .grad tensors; nothing for autograd to accumulate
+            for k in range(self.nblk):
+                g = self.grads[k]
+                for j, name in enumerate(PARAM_FIELDS):
+                    p = fused_into[k * NP + j]
+                    setattr(g, name, None if p is None else p.grad.data_ptr())
+            return None, [None] * len(params)
         if flat is None:
             flat = torch.zeros(max(total, 1), dtype=torch.float32, device=device)
         base = flat.data_ptr()
@@ -173,6 +208,7 @@ class _CemlpFn(torch.autograd.Function):
                                                x.data_ptr(), rows, y.data_ptr(), _ptr(saved), ws.data_ptr(),
                                                ws.numel(), 0, _stream(x.device)))
         ctx.binding = binding
+        ctx.param_refs = params          # the caller's parameter objects (their .grad, for fused accumulation)
         ctx.ws, ctx.saved = ws, saved   # packed weights / block inputs are reused by backward
         ctx.save_for_backward(x, *[p for p in params if p is not None])
         ctx.mask = [p is not None for p in params]
@@ -187,7 +223,8 @@ class _CemlpFn(torch.autograd.Function):
         params = [next(it) if m else None for m in ctx.mask]
         gy = gy.contiguous()
         binding.bind(params)
-        flat, views = binding.new_grads(params, x.device)
+        fused = ctx.param_refs if _fusable(ctx.param_refs, x.device) else None
+        flat, views = binding.new_grads(params, x.device, fused_into=fused)
         gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = ctx.ws
         check(native.lib().csmpn_cemlp_backward(binding.metric_arr, binding.n, binding.params, binding.grads,
@@ -400,13 +437,13 @@ class HipBackend:
 
     @staticmethod
     @_on_device_of(2)
-    def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None, gflat=None):
+    def node_backward(spec, deg, h, agg, node_attr, pn, gout, want_gna, state=None, gflat=None, fused_into=None):
         """state: the workspace node_forward returned (its packed weights are reused);
         gflat: optional zeroed flat gradient buffer (CemlpBinding.grad_floats elements)."""
         nd = spec.node
         nd.bind(pn)
         N, D, dev = h.shape[0], nd.D, h.device
-        _flat, views = nd.new_grads(pn, dev, gflat)
+        _flat, views = nd.new_grads(pn, dev, gflat, fused_into=fused_into)
         gh = torch.empty_like(h)
         g_agg = torch.empty(N, spec.O, D, dtype=torch.float32, device=dev)
         g_na = torch.empty_like(node_attr) if (node_attr is not None and want_gna) else None
@@ -420,12 +457,12 @@ class HipBackend:
 
     @staticmethod
     @_on_device_of(2)
-    def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None, gflat=None):
+    def edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, want_gea, state=None, gflat=None, fused_into=None):
         """gh is accumulated in place (+= scatter of +-d/d(h_i - h_j)); gflat as in node_backward."""
         e = spec.edge
         e.bind(pe)
         N, dev = h.shape[0], h.device
-        _flat, views = e.new_grads(pe, dev, gflat)
+        _flat, views = e.new_grads(pe, dev, gflat, fused_into=fused_into)
         g_ea = torch.empty_like(edge_attr) if (edge_attr is not None and want_gea) else None
         ws, saved = state if state is not None else (e.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
@@ -480,7 +517,9 @@ class _EgclFn(torch.autograd.Function):
         # will follow, both models' flat gradient buffers
         spec.edge.bind(pe); spec.node.bind(pn)
         n_agg = h.shape[0] * spec.O * spec.edge.D
-        n_ge, n_gn = (spec.edge.grad_floats(pe), spec.node.grad_floats(pn)) if any(ctx.needs_input_grad) else (0, 0)
+        ctx.param_refs = params
+        fuse = _fusable(params, h.device)   # gradients go straight into p.grad: no flat buffers to zero
+        n_ge, n_gn = (spec.edge.grad_floats(pe), spec.node.grad_floats(pn)) if (any(ctx.needs_input_grad) and not fuse) else (0, 0)
         zeros = torch.zeros(n_agg + n_ge + n_gn, dtype=torch.float32, device=h.device)
         agg = zeros[:n_agg].view(h.shape[0], spec.O, spec.edge.D)
         ctx.gflats = (zeros[n_agg:n_agg + n_ge], zeros[n_agg + n_ge:]) if n_ge else None
@@ -515,10 +554,13 @@ class _EgclFn(torch.autograd.Function):
         gout = gout.contiguous()
         gfe, gfn = ctx.gflats if ctx.gflats is not None else (None, None)
         ctx.gflats = None   # zeroed once: a second backward through the same graph allocates afresh
+        refs = ctx.param_refs
+        fuse = _fusable(refs, h.device)
         gh, g_agg, g_na, views_n = HipBackend.node_backward(spec, csr.deg, h, agg, node_attr, pn, gout,
-                                                            ctx.needs_input_grad[2], ctx.st_n, gfn)
+                                                            ctx.needs_input_grad[2], ctx.st_n, gfn,
+                                                            fused_into=refs[ne:] if fuse else None)
         g_ea, views_e = HipBackend.edge_backward(spec, csr, h, edge_attr, pe, g_agg, gh, ctx.needs_input_grad[1],
-                                                 ctx.st_e, gfe)
+                                                 ctx.st_e, gfe, fused_into=refs[:ne] if fuse else None)
         return (gh, g_ea, g_na, None, None, *views_e, *views_n)
 
 

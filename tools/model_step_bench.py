@@ -26,11 +26,14 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--points", type=int, default=8)
+    ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     args = ap.parse_args()
     importlib.import_module(PKG)
     from csmpn.data import complexes as cx
     from csmpn.models import simplicial_mpnn as M
     from csmpn_hip.graphed import GraphedTrainStep
+    from csmpn_hip import ops
+    ops.set_fused_grad_accumulation(not args.no_fused_grads)
 
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
@@ -67,7 +70,7 @@ def main():
     graph_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     print(json.dumps({"model": "hulls (Cl(5,0), 28 channels, 3 layers)", "graphs_per_batch": args.batch,
                       "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
-                      "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
+                      "fused_grad_accumulation": not args.no_fused_grads, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
                       "loss": float(gs.loss.detach())}))
 
 
