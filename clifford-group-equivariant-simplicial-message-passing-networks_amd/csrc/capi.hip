@@ -594,7 +594,7 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     return true;
 }
 
-int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st) {
+int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st, bool need_pack) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
@@ -658,6 +658,11 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         return fail(CSMPN_ERR_UNSUPPORTED,
                     "CSMPN_FLAG_DETERMINISTIC needs the row-per-lane kernels (Cl(3,0), 8 or 16 channels, <= 2 blocks, "
                     "saved block inputs): the other kernel families sum parameter gradients with float atomics");
+    // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
+    if (need_pack) {
+        const int rcp = run_pack(plan, st);
+        if (rcp) return rcp;
+    }
     const long R = 16 * plan.H;
     const long ntiles = (io.rows + R - 1) / R;
     // few tiles (e.g. the node update of a 10k-node complex): fewer row tiles per workgroup,
@@ -903,13 +908,13 @@ int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* bl
     Plan plan;
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, rows, plan);
     if (rc) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.y = y; io.save = save_inputs;
-    return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream, need_pack);
 }
 
 int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
@@ -923,13 +928,13 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
     (void)flags;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = true;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
-    return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
 }
 
 int csmpn_mvlinear_forward(int n, const float* x, const float* weight, const float* bias, int64_t rows,
@@ -985,7 +990,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false,
                        blocks[n_blocks - 1].out_features * D, false, E, plan);
     if (rc) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
@@ -994,7 +999,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm; io.save = save_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // agg is then the [E, O, D] message table
     (void)N;
-    return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream, need_pack);
 }
 
 int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_params* blocks,
@@ -1013,7 +1018,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     if (rc) return rc;
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = true;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = E; io.nseg = attr_channels > 0 ? 2 : 1;
@@ -1023,7 +1028,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // gh is then the [E, C, D] per-edge gradient table
     (void)N;
-    return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream, need_pack);
 }
 
 static int node_io(const csmpn_block_params* blocks, int n_blocks, const float* h, int channels, const float* agg,
@@ -1057,9 +1062,9 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, N, plan))) return rc;
-    if (!(flags & CSMPN_FLAG_WEIGHTS_PACKED) && (rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     io.y = out; io.resid = residual ? h : nullptr; io.save = save_inputs;
-    return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream, need_pack);
 }
 
 int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_params* blocks,
@@ -1079,10 +1084,10 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
     (void)flags;
-    if ((rc = run_pack(plan, (hipStream_t)stream))) return rc;
+    const bool need_pack = true;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
-    return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream);
+    return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream, need_pack);
 }
 
 }  // extern "C"
