@@ -42,6 +42,8 @@ WORKLOADS = {
     "S1": ((1.0, 1.0, 1.0), 8, 10_000, 100_000),
     "S2": ((1.0, 1.0, 1.0), 16, 100_000, 1_000_000),
     "S3": ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000),
+    # not a BASELINE throughput config: one layer of the convex-hulls width (Cl(5,0), 28 channels) at S1's size
+    "H28": ((1.0, 1.0, 1.0, 1.0, 1.0), 28, 10_000, 100_000),
 }
 
 

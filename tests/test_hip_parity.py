@@ -457,6 +457,49 @@ def test_scatter_linearity_full_size(pkg):
     assert torch.isfinite(full).all()
 
 
+@pytest.mark.parametrize("metric,C,N,E", [
+    ((1.0, 1.0, 1.0), 8, 10_000, 100_000),                # S1 (row-per-lane kernels)
+    ((1.0, 1.0, 1.0), 16, 100_000, 1_000_000),            # S2 at its full 1 M-edge size
+    ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000),     # S3 (parity-lane kernels)
+    ((1.0,) * 5, 28, 5_000, 50_000),                      # the convex-hulls width (wide parity-lane kernels)
+])
+def test_edge_stage_additivity_full_size(pkg, metric, C, N, E):
+    """Size-independent property at BASELINE's full sizes (no oracle in the loop): with the node side fixed, the edge
+    stage - forward aggregate, the scattered d/dh and every parameter gradient of the edge model - is additive over a
+    partition of the edge list. Exercises the tile loops, the tails, the scatters and the gradient reductions of every
+    kernel family at sizes the oracle cannot reach."""
+    from csmpn_hip import ops
+    D = 1 << len(metric)
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra(tuple(metric)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="sum",
+                     residual=False).to(dev())
+    h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=0))
+    if min(metric) < 0:   # keep the indefinite metric away from the null cone (see test_egcl_cl41_well_conditioned)
+        bits = sum(1 << i for i, m in enumerate(metric) if m < 0)
+        mask = torch.from_numpy(((np.asarray(O.Algebra(list(metric)).t.index_to_bitmap) & bits) != 0).astype(np.float32)).to(dev())
+        h = h * (1.0 - mask + 0.02 * mask)
+    be, spec = ops.HipBackend, layer.spec()
+    pe = layer.edge_model.flat_params()
+    g_agg = torch.randn(N, C, D, device=dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+
+    def run(sel):
+        csr = ops.Csr(ei[:, sel].contiguous(), N)
+        eas = ea[sel].contiguous()
+        agg, st = be.edge_forward(spec, csr, h, eas, pe)
+        gh = torch.zeros_like(h)
+        _g_ea, views = be.edge_backward(spec, csr, h, eas, pe, g_agg, gh, False, st)
+        torch.cuda.synchronize()
+        return [agg, gh] + [v.clone() for v in views if v is not None]
+
+    idx = torch.arange(E, device=dev())
+    full = run(idx)
+    a, b = run(idx[: E // 3]), run(idx[E // 3:])
+    for i, (f, x, y) in enumerate(zip(full, a, b)):
+        assert torch.isfinite(f).all()
+        tol = 1e-5 if i < 2 else 1e-4      # parameter gradients are sums over up to a million edges
+        assert relmax((x + y).cpu().numpy(), f.cpu().numpy()) < tol, f"tensor {i}"
+
+
 def test_csr_build(pkg):
     from csmpn_hip import ops
     g = torch.Generator().manual_seed(3)
