@@ -41,6 +41,21 @@ CSMPN_DEV float pl_rot(float v) {
         return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0x120 + 2 * R, 0xF, 0xF, true));
     }
 }
+// acc += w * (value of x in the lane that rotation R brings here): ONE v_fmac_f32_dpp. hipcc folds a DPP move into
+// v_add / v_mul but not into v_fmac (tied accumulator), which would leave the mixing at two instructions per term.
+// Inline asm is opaque to the hazard recognizer (a DPP read needs 2 wait states after a VALU write of its source,
+// 5 after an EXEC write): pl_dpp_ready() in front of a run of these orders the producers of x before an s_nop 4,
+// and the statements are volatile so that the run stays behind it.
+template <int R>
+CSMPN_DEV void pl_fmac_rot(float& acc, float x, float w) {
+    if constexpr (R == 0) acc = __builtin_fmaf(w, x, acc);
+    else asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                      : "+v"(acc) : "v"(x), "v"(w), "n"(2 * R));
+}
+CSMPN_DEV void pl_dpp_ready(const float (&x)[16]) {
+    asm volatile("s_nop 4" :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+                             "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]), "v"(x[15]));
+}
 CSMPN_DEV float pl_partner(float v) { return dpp_mov<0xB1>(v); }   // quad_perm [1,0,3,2]: the other parity
 CSMPN_DEV float pl_even(float v) { return dpp_mov<0xA0>(v); }      // quad_perm [0,0,2,2]: the even lane's value in both
 CSMPN_DEV float pl_odd(float v) { return dpp_mov<0xF5>(v); }       // quad_perm [1,1,3,3]
@@ -181,6 +196,8 @@ CSMPN_DEV void pl_linear(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int k = 0; k < GC; ++k) w[r][k] = ldsn[OFF + (r * GC + k) * 16];
+    // (two instructions per term: the v_fmac_f32_dpp form of cemlp_plw.hpp pins its operands to arch VGPRs and
+    // costs the 8-channel backward 400-570 B of scratch - measured slower: edge backward 883 -> 1299 us)
     static_for<0, 8>([&](auto r) {
         static_for<0, DL>([&](auto jj) {
             constexpr int j = decltype(jj)::value;

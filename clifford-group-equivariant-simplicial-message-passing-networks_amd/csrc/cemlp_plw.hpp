@@ -133,11 +133,12 @@ template <class ALG>
 CSMPN_DEV void plw_mix_w(float (&acc)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL], const f4 (&wv)[6]) {
     using P = PS<ALG>;
     constexpr int GC = P::GC, DL = P::DL;
+    pl_dpp_ready(x);
     static_for<0, 8>([&](auto r) {
         static_for<0, DL>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
             constexpr int f = decltype(r)::value * GC + P::t.cls[j];
-            acc[j] = __builtin_fmaf(wv[f / 4][f % 4], pl_rot<decltype(r)::value>(x[j]), acc[j]);
+            pl_fmac_rot<decltype(r)::value>(acc[j], x[j], wv[f / 4][f % 4]);
         });
         pl_pin<0, DL>(acc);
     });
@@ -147,13 +148,13 @@ CSMPN_DEV void plw_mix2_w(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL]
                           const f4 (&wa)[6], const f4 (&wb)[6]) {
     using P = PS<ALG>;
     constexpr int GC = P::GC, DL = P::DL;
+    pl_dpp_ready(x);
     static_for<0, 8>([&](auto r) {
         static_for<0, DL>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
             constexpr int f = decltype(r)::value * GC + P::t.cls[j];
-            const float t = pl_rot<decltype(r)::value>(x[j]);
-            accA[j] = __builtin_fmaf(wa[f / 4][f % 4], t, accA[j]);
-            accB[j] = __builtin_fmaf(wb[f / 4][f % 4], t, accB[j]);
+            pl_fmac_rot<decltype(r)::value>(accA[j], x[j], wa[f / 4][f % 4]);
+            pl_fmac_rot<decltype(r)::value>(accB[j], x[j], wb[f / 4][f % 4]);
         });
         pl_pin<0, DL>(accA);
         pl_pin<0, DL>(accB);
