@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--points", type=int, default=8)
+    ap.add_argument("--model", default="hulls", choices=["hulls", "md17"])
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     args = ap.parse_args()
@@ -38,10 +39,31 @@ def main():
 
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(0)
-    batch = cx.collate([cx.hulls_example(rng.standard_normal((args.points, 5)).astype(np.float32))
-                        for _ in range(args.batch)]).to(dev)
+    if args.model == "hulls":
+        batch = cx.collate([cx.hulls_example(rng.standard_normal((args.points, 5)).astype(np.float32))
+                            for _ in range(args.batch)]).to(dev)
+        features = ["input", "target"]
+    else:
+        # MD17-shaped batch (md17_cssmpnn.py; csmpn/configs/md17.yaml: Cl(3,0), 32 channels, 5 layers): 21 atoms
+        # (aspirin), 10 frames, Vietoris-Rips complex of the first frame, random positions / velocities / charges
+        V, F, graphs = 21, 10, []
+        for _ in range(args.batch):
+            base = (1.6 * rng.standard_normal((V, 3))).astype(np.float32)
+            c = cx.rips_complex(base, dis=1.8, max_dim=2)
+            S = c.n_simplices
+            loc = torch.zeros(S, F, 3); vel = torch.zeros(S, F, 3); ch = torch.zeros(S, F, 1)
+            loc[:V] = torch.from_numpy(base)[:, None, :] + 0.05 * torch.from_numpy(rng.standard_normal((V, F, 3)).astype(np.float32))
+            vel[:V] = 0.1 * torch.from_numpy(rng.standard_normal((V, F, 3)).astype(np.float32))
+            ch[:V] = torch.from_numpy(rng.integers(1, 9, size=(V, 1, 1)).astype(np.float32)).expand(V, F, 1)
+            c.features.update(loc=loc, vel=vel, charges=ch)
+            graphs.append(c)
+        batch = cx.collate(graphs)
+        batch.y = torch.cat([g.features["loc"][: g.n_vertices] + 0.1 * torch.randn(g.n_vertices, F, 3) for g in graphs], dim=0)
+        batch._names.append("y")
+        batch = batch.to(dev)
+        features = ["loc", "vel", "charges", "y"]
     torch.manual_seed(0)
-    model = M.HullsSimplicialMPNN().to(dev)
+    model = (M.HullsSimplicialMPNN() if args.model == "hulls" else M.MD17SimplicialMPNN()).to(dev)
     # the reference trains with torch.optim.Adam (csmpn/configs/hulls.yaml); fused=True is the same update in one
     # multi-tensor kernel (the default foreach path with capturable=True issues ~300 per-tensor div kernels: 1.5 ms)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True,
@@ -63,7 +85,7 @@ def main():
     torch.cuda.synchronize()
     eager_ms = (time.perf_counter() - t0) * 1e3 / args.steps
 
-    gs = GraphedTrainStep(model, opt, batch, ["input", "target"])
+    gs = GraphedTrainStep(model, opt, batch, features)
     for _ in range(5):
         gs.step()
     torch.cuda.synchronize()
@@ -72,7 +94,7 @@ def main():
         gs.step()
     torch.cuda.synchronize()
     graph_ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    print(json.dumps({"model": "hulls (Cl(5,0), 28 channels, 3 layers)", "graphs_per_batch": args.batch,
+    print(json.dumps({"model": "hulls (Cl(5,0), 28 channels, 3 layers)" if args.model == "hulls" else "md17 (Cl(3,0), 32 channels, 5 layers)", "graphs_per_batch": args.batch,
                       "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
                       "fused_grad_accumulation": not args.no_fused_grads, "fused_adam": not args.no_fused_adam, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
                       "loss": float(gs.loss.detach())}))

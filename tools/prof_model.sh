@@ -4,7 +4,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_hulls_model
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/model_step_bench.py --steps 10 > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/model_step_bench.py --steps 10 $MODEL_ARGS > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
