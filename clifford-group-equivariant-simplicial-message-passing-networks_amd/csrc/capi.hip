@@ -507,7 +507,8 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
 // ... and of the backward's partial buffer: one slice of weight-gradient MFMA tiles per workgroup (upper bound)
 size_t plw_part_bytes(int ch) {
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
-    return (nch0 + 2 * NG) * 12 * 64 * NG * sizeof(float) * kPlwMaxGroups + 256;
+    const size_t image = 8 * NG * (3 + 3 * 6 + 64) + 16;   // per-channel sums (CP x (3 + 3 G + P)), generous
+    return ((nch0 + 2 * NG) * 12 * 64 * NG + image) * sizeof(float) * kPlwMaxGroups + 256;
 }
 size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 5 || nblk < 1 || nblk > 2) return 0;
@@ -585,7 +586,6 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
         na = C.b[0].I;                      // standalone CEMLP: its (<= 8) input channels are the one input chunk
         if (na < 1 || na > 8 || io.nseg != 1) return false;
     }
-    if (io.row_store) return false;
     const size_t tf = id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, ch, na, C.nblk) : cemlp_plw_table_floats_n5m(mode, ch, na, C.nblk);
     if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + plw_part_bytes(ch) + 1024) return false;
     if (bwd && C.nblk > 1 && !io.saved) return false;
@@ -656,8 +656,9 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     }
     if (io.row_store)
         return fail(CSMPN_ERR_UNSUPPORTED,
-                    "CSMPN_FLAG_DETERMINISTIC needs the row-per-lane kernels (Cl(3,0), 8 or 16 channels, <= 2 blocks, "
-                    "saved block inputs): the other kernel families sum parameter gradients with float atomics");
+                    "CSMPN_FLAG_DETERMINISTIC needs the row-per-lane kernels (Cl(3,0), 8 or 16 channels) or the wide parity-lane "
+                    "kernels (Cl(5,0) / Cl(4,1), 16 / 24 / 28 / 32 channels), two blocks with saved block inputs: the other "
+                    "kernel families sum parameter gradients with float atomics");
     // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
     if (need_pack) {
         const int rcp = run_pack(plan, st);

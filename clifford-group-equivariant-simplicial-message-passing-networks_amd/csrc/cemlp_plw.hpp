@@ -417,6 +417,14 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 
             int tg[kPlRows];
 #pragma unroll
             for (int r = 0; r < kPlRows; ++r) tg[r] = __builtin_amdgcn_readlane(i_dst, 16 * r);
+            if (io.row_store) {   // deterministic mode: the message rows go to an [E, C, D] table in sorted edge order
+                for (int r = 0; r < kPlRows; ++r) {
+                    const long rr = tile * kPlRows + r;
+                    if (rr < io.rows)
+                        for (int e = 4 * threadIdx.x; e < ROW; e += 4 * NT)
+                            *reinterpret_cast<f4*>(io.agg + (size_t)rr * ROW + e) = pl_ld4(stg + r * RS + e);
+                }
+            } else
             for (int col = threadIdx.x; col < ROW; col += NT) {
                 float acc = 0.f;
                 int cur = tg[0];
@@ -585,7 +593,12 @@ struct PlwPart {
     static constexpr int GC = CF::GC, NG = CF::NG, NT = 64 * CF::NG;
     static constexpr int n_tiles = NIN + 2 * NG;                 // (W1: NIN input groups) + (WR, WL: NG each)
     static constexpr int slots = n_tiles * GC * 4;
-    static constexpr int slice = slots * NT;                     // floats per workgroup
+    static constexpr int w_floats = slots * NT;                  // MFMA tiles
+    // ... followed by the image of the per-channel sums: b1, bL, la [CP each], sa, sb, an [CP x G each], w [CP x P]
+    static constexpr int CP = CF::CP, G = CF::G, NP = CF::NP;
+    static constexpr int i_b1 = 0, i_bL = CP, i_la = 2 * CP, i_sa = 3 * CP, i_sb = i_sa + CP * G, i_an = i_sb + CP * G,
+                         i_w = i_an + CP * G, i_tot = i_w + CP * NP;
+    static constexpr int slice = (w_floats + i_tot + 3) & ~3;    // floats per workgroup
     static constexpr int tile_of(int table, int ig) { return table == 0 ? ig : (table == 1 ? NIN + ig : NIN + NG + ig); }
 };
 template <class ALG, class CF, int BLK>
@@ -606,8 +619,9 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
     __shared__ float red[4][64];
     const int sub = threadIdx.x >> 6;
     const long t = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool in = t < PP::slice;
-    const int tid = (int)(t % NT), slot = (int)(t / NT);
+    const bool in = t < PP::w_floats + PP::i_tot;
+    const bool small = t >= PP::w_floats;
+    const int tid = (int)(t % NT), slot = small ? 0 : (int)(t / NT);
     const int v = slot & 3, k = (slot >> 2) % GC, tile_idx = (slot >> 2) / GC;
     int table, ig;
     if (tile_idx < PP::NIN) { table = 0; ig = tile_idx; }
@@ -620,7 +634,25 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
     else { base = 8 * ig; nvalid = C - 8 * ig < 8 ? C - 8 * ig : 8; I = C; }
     const DevBlock& B = Cd.b[BLK];
     float* gW = table == 0 ? B.gW1 : (table == 1 ? B.gWR : B.gWL);
-    const bool live = in && so == s && o < C && c < nvalid && gW != nullptr;
+    bool live = in && !small && so == s && o < C && c < nvalid && gW != nullptr;
+    float* dst = nullptr;
+    if (live) {
+        const int grade = s ? ALG::n - 2 * k : 2 * k;
+        dst = gW + ((size_t)o * I + base + c) * G + grade;
+    }
+    if (in && small) {   // per-channel sums: image entry -> (tensor, element); channels beyond C are padding
+        const int e = (int)(t - PP::w_floats);
+        constexpr int CPc = CF::CP, NPc = ALG::P;
+        if (e < PP::i_bL) { if (e < C && B.has_b1 && B.gb1) dst = B.gb1 + e; }
+        else if (e < PP::i_la) { if (e - PP::i_bL < C && B.gbL) dst = B.gbL + (e - PP::i_bL); }
+        else if (e < PP::i_sa) { if (e - PP::i_la < C && B.gla) dst = B.gla + (e - PP::i_la); }
+        else if (e < PP::i_sb) { if (e - PP::i_sa < C * G && B.gsa) dst = B.gsa + (e - PP::i_sa); }
+        else if (e < PP::i_an) { if (e - PP::i_sb < C * G && B.gsb) dst = B.gsb + (e - PP::i_sb); }
+        else if (e < PP::i_w) { if (e - PP::i_an < C * G && B.gan) dst = B.gan + (e - PP::i_an); }
+        else { if (e - PP::i_w < C * NPc && B.gw) dst = B.gw + (e - PP::i_w); }
+        (void)CPc;
+        live = dst != nullptr;
+    }
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (live) {
         const float* p = part + t;
@@ -637,8 +669,7 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
     __syncthreads();
     if (sub == 0 && live) {
         const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        const int grade = s ? ALG::n - 2 * k : 2 * k;
-        gW[((size_t)o * I + base + c) * G + grade] += sum;
+        *dst += sum;
     }
 }
 
@@ -842,7 +873,9 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                     }
                     pl_stage<ALG>(stg + 8 * wave * D, gx, ge, RS, cvalid);
                     __syncthreads();
-                    if constexpr (MODE == MODE_EDGE) {
+                    if (MODE == MODE_EDGE && io.row_store) {
+                        copy_rows(dstp, ROW, [&](int, long rr) { return rr; });   // deterministic mode: per-edge rows
+                    } else if constexpr (MODE == MODE_EDGE) {
                         int td[kPlRows], ts[kPlRows];
 #pragma unroll
                         for (int r = 0; r < kPlRows; ++r) {
@@ -908,45 +941,49 @@ __global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const Dev
                 plw_store_tile<ALG, CF, BLK>(slice, PP::tile_of(2, decltype(jc)::value), aWL[decltype(jc)::value], threadIdx.x);
             });
         }
-        // small sums: lanes -> LDS image (the exchange buffers are free now) -> one round of global atomics
-        constexpr int i_b1 = 0, i_bL = CP, i_la = 2 * CP, i_sa = 3 * CP, i_sb = i_sa + CP * G, i_an = i_sb + CP * G,
-                      i_w = i_an + CP * G, i_tot = i_w + CP * ALG::P;
-        static_assert(i_tot <= CF::NXB * CF::XB, "image fits the exchange buffers");
-        float* img = lds + CF::x_off(0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < i_tot; e += NT) img[e] = 0.f;
-        __syncthreads();
-        const int c = 8 * wave + ge.c;
-        atomicAdd(img + i_la + c, tot[SI::la * NT]);
-        if (ge.s == 0) {
-            atomicAdd(img + i_bL + c, tot[SI::bL * NT]);
-            atomicAdd(img + i_b1 + c, tot[SI::b1 * NT]);
-        }
+        // small sums: every (row quarter, lane column) writes its value to its own slot of a 4-fold LDS image (the
+        // exchange buffers are free now; exactly one writer per slot, no atomics), the quarters are added in a fixed
+        // order and the image goes to the tail of the workgroup's slice: plw_reduce_kernel adds the slices
+        {
+            using PP = PlwPart<CF, BLK>;
+            constexpr int L_b1 = 0, L_bL = CP, L_la = 2 * CP, L_sa = 4 * CP, L_sb = L_sa + CP * G, L_an = L_sb + CP * G,
+                          L_w = L_an + CP * G, L_tot = L_w + CP * ALG::P;      // la holds [c][parity] here
+            static_assert(4 * L_tot <= CF::NXB * CF::XB, "4-fold image fits the exchange buffers");
+            float* img = lds + CF::x_off(0);
+            __syncthreads();
+            for (int e = threadIdx.x; e < 4 * L_tot; e += NT) img[e] = 0.f;
+            __syncthreads();
+            float* mine = img + ge.q * L_tot;
+            const int c = 8 * wave + ge.c;
+            mine[L_la + 2 * c + ge.s] = tot[SI::la * NT];
+            if (ge.s == 0) {
+                mine[L_bL + c] = tot[SI::bL * NT];
+                mine[L_b1 + c] = tot[SI::b1 * NT];
+            }
 #pragma unroll
-        for (int k = 0; k < GC; ++k) {
-            const int pg = c * G + ge.grade(k);
-            atomicAdd(img + i_an + pg, tot[(SI::an + k) * NT]);
-            atomicAdd(img + i_sa + pg, tot[(SI::sa + k) * NT]);
-            atomicAdd(img + i_sb + pg, tot[(SI::sb + k) * NT]);
+            for (int k = 0; k < GC; ++k) {
+                const int pg = c * G + ge.grade(k);
+                mine[L_an + pg] = tot[(SI::an + k) * NT];
+                mine[L_sa + pg] = tot[(SI::sa + k) * NT];
+                mine[L_sb + pg] = tot[(SI::sb + k) * NT];
+            }
+            static_for<0, P::QP>([&](auto qq) {
+                constexpr int q = decltype(qq)::value;
+                mine[L_w + c * ALG::P + (ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q])] = tot[(SI::wA + q) * NT];
+                mine[L_w + c * ALG::P + (ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q])] =
+                    tot[(SI::wB + q) * NT] * (ge.s ? 1.0f : float(P::t.I2));
+            });
+            __syncthreads();
+            float* tail = io.plw_part + (size_t)blockIdx.x * PP::slice + PP::w_floats;
+            auto quarters = [&](int l) { return (img[l] + img[L_tot + l]) + (img[2 * L_tot + l] + img[3 * L_tot + l]); };
+            for (int e = threadIdx.x; e < PP::i_tot; e += NT) {
+                float v;
+                if (e < PP::i_la) v = quarters(e);                                    // b1, bL: same offsets
+                else if (e < PP::i_sa) v = quarters(L_la + 2 * (e - PP::i_la)) + quarters(L_la + 2 * (e - PP::i_la) + 1);
+                else v = quarters(L_sa + (e - PP::i_sa));                           // sa, sb, an, w: same order
+                tail[e] = v;
+            }
         }
-        static_for<0, P::QP>([&](auto qq) {
-            constexpr int q = decltype(qq)::value;
-            atomicAdd(img + i_w + c * ALG::P + (ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q]), tot[(SI::wA + q) * NT]);
-            atomicAdd(img + i_w + c * ALG::P + (ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q]),
-                      tot[(SI::wB + q) * NT] * (ge.s ? 1.0f : float(P::t.I2)));
-        });
-        __syncthreads();
-        auto flush = [&](float* dst, int off, int n) {
-            if (dst)
-                for (int e = threadIdx.x; e < n; e += NT) atomicAdd(dst + e, img[off + e]);
-        };
-        if (B.has_b1) flush(B.gb1, i_b1, C);
-        flush(B.gbL, i_bL, C);
-        flush(B.gla, i_la, C);
-        flush(B.gsa, i_sa, C * G);
-        flush(B.gsb, i_sb, C * G);
-        flush(B.gan, i_an, C * G);
-        flush(B.gw, i_w, C * ALG::P);
     }
 }
 

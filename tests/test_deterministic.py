@@ -62,8 +62,9 @@ def test_source_order(pkg):
     assert rp[0] == 0 and rp[-1] == E
 
 
-def _run_layer(pkg, C, seed, N=2000, E=20000):
-    alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+def _run_layer(pkg, C, seed, N=2000, E=20000, metric=(1.0, 1.0, 1.0)):
+    alg = pkg.CliffordAlgebra(tuple(metric))
+    D = 1 << len(metric)
     torch.manual_seed(seed)
     layer = pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
     g = torch.Generator().manual_seed(seed)
@@ -72,10 +73,10 @@ def _run_layer(pkg, C, seed, N=2000, E=20000):
     ei[0, E // 4: E // 2] = 9                    # and a quarter share one source
     ei[:, -50:] = ei[:, -100:-50]                # duplicates
     ei = ei.to(dev())
-    h = torch.randn(N, C, 8, generator=g).to(dev())
-    ea = torch.randn(E, 6, 8, generator=g).to(dev())
-    na = torch.randn(N, 3, 8, generator=g).to(dev())
-    gout = torch.randn(N, C, 8, generator=g).to(dev())
+    h = torch.randn(N, C, D, generator=g).to(dev())
+    ea = torch.randn(E, 6, D, generator=g).to(dev())
+    na = torch.randn(N, 3, D, generator=g).to(dev())
+    gout = torch.randn(N, C, D, generator=g).to(dev())
 
     def once():
         hh, e2, n2 = h.clone().requires_grad_(True), ea.clone().requires_grad_(True), na.clone().requires_grad_(True)
@@ -89,9 +90,11 @@ def _run_layer(pkg, C, seed, N=2000, E=20000):
     return once
 
 
-@pytest.mark.parametrize("C", [8, 16])
-def test_bit_reproducible(pkg, det, C):
-    once = _run_layer(pkg, C, seed=11)
+@pytest.mark.parametrize("C,metric,N,E", [(8, (1.0, 1.0, 1.0), 2000, 20000), (16, (1.0, 1.0, 1.0), 2000, 20000),
+                                          # the wide parity-lane kernels: the convex-hulls width, and Cl(4,1)
+                                          (28, (1.0,) * 5, 400, 4000), (16, (1.0, 1.0, 1.0, 1.0, -1.0), 300, 3000)])
+def test_bit_reproducible(pkg, det, C, metric, N, E):
+    once = _run_layer(pkg, C, seed=11, N=N, E=E, metric=metric)
     a = once()
     for _ in range(3):
         b = once()
@@ -115,9 +118,10 @@ def test_matches_atomic_mode(pkg, C):
         assert float((x - y).abs().max()) <= 2e-5 * scale, f"tensor {i}"
 
 
-@pytest.mark.parametrize("C,aggr", [(8, "mean"), (16, "sum")])
-def test_parity_vs_oracle(pkg, det, C, aggr):
-    _oracle_egcl_case([1.0, 1.0, 1.0], 300, 2999, C, C, aggr, seed=5)
+@pytest.mark.parametrize("metric,C,aggr,N,E", [((1.0, 1.0, 1.0), 8, "mean", 300, 2999), ((1.0, 1.0, 1.0), 16, "sum", 300, 2999),
+                                               ((1.0,) * 5, 28, "mean", 120, 1001)])
+def test_parity_vs_oracle(pkg, det, metric, C, aggr, N, E):
+    _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=5)
 
 
 def test_unsupported_shape(pkg, monkeypatch):
