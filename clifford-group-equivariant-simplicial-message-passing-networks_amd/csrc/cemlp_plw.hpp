@@ -233,7 +233,9 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
 #pragma unroll
     for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
     float* xb = lds + CF::x_off(0);
-    __syncthreads();                      // the buffer's previous readers are done
+    // no barrier in front of the put: every earlier reader of buffer 0 (the previous block's / tile's mixing and
+    // weight-gradient reads) is followed by a workgroup barrier in program order (LayerNorm exchange, gradient
+    // exchanges, row stores), so all waves have left those reads before any wave gets here
     plw_put<ALG>(xb, wave, ge.lane, z);
     __syncthreads();
     {
@@ -497,7 +499,8 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     float gz[DL];
 #pragma unroll
     for (int j = 0; j < DL; ++j) gz[j] = 0.f;
-    __syncthreads();
+    // (no barrier in front: the previous readers of buffer 2 - the last tile's d/d(MVLinear output) exchange - are
+    // followed by the row-store barriers and this tile's forward barriers)
     plw_put<ALG>(xb2, wave, ge.lane, ggp);
     __syncthreads();
     plw_mix_loop<ALG>(gz, tabs + CF::t_WLt(K) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
