@@ -429,10 +429,18 @@ class HipBackend:
         out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
         ws = nd.workspace(h.device)
         saved = nd.new_saved(N, h.device) if save else None
-        check(native.lib().csmpn_egcl_node_forward(
-            nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
-            _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, out.data_ptr(),
-            _ptr(saved), ws.data_ptr(), ws.numel(), 0, _stream(h.device)))
+
+        def call(flags):
+            return native.lib().csmpn_egcl_node_forward(
+                nd.metric_arr, nd.n, nd.params, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
+                _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, out.data_ptr(),
+                _ptr(saved), ws.data_ptr(), ws.numel(), flags, _stream(h.device))
+
+        det = deterministic_request()   # node stage: the flag only selects kernels with atomic-free parameter sums
+        rc = call(native.FLAG_DETERMINISTIC if det else 0)
+        if det == "soft" and _soft_fallback(rc):
+            rc = call(0)
+        check(rc)
         return out, (ws, saved)
 
     @staticmethod
@@ -449,10 +457,18 @@ class HipBackend:
         g_na = torch.empty_like(node_attr) if (node_attr is not None and want_gna) else None
         ws, saved = state if state is not None else (nd.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
-        check(native.lib().csmpn_egcl_node_backward(
-            nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
-            _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, gout.data_ptr(),
-            gh.data_ptr(), g_agg.data_ptr(), _ptr(g_na), _ptr(saved), ws.data_ptr(), ws.numel(), flags, _stream(dev)))
+
+        def call(fl):
+            return native.lib().csmpn_egcl_node_backward(
+                nd.metric_arr, nd.n, nd.params, nd.grads, nd.nblk, h.data_ptr(), spec.C, agg.data_ptr(), spec.O,
+                _ptr(node_attr), spec.T, deg.data_ptr(), spec.mean, spec.residual, N, gout.data_ptr(),
+                gh.data_ptr(), g_agg.data_ptr(), _ptr(g_na), _ptr(saved), ws.data_ptr(), ws.numel(), fl, _stream(dev))
+
+        det = deterministic_request()
+        rc = call(flags | (native.FLAG_DETERMINISTIC if det else 0))
+        if det == "soft" and _soft_fallback(rc):
+            rc = call(flags)
+        check(rc)
         return gh, g_agg, g_na, views
 
     @staticmethod

@@ -508,12 +508,13 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
 size_t plw_part_bytes(int ch) {
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
     const size_t image = 8 * NG * (3 + 3 * 6 + 64) + 16;   // per-channel sums (CP x (3 + 3 G + P)), generous
-    return ((nch0 + 2 * NG) * 12 * 64 * NG + image) * sizeof(float) * kPlwMaxGroups + 256;
+    const size_t per_cu = 4 / NG > 0 ? 4 / NG : 1;
+    return ((nch0 + 2 * NG) * 12 * 64 * NG + image) * sizeof(float) * kPlwMaxGroups * per_cu + 256;
 }
 size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 5 || nblk < 1 || nblk > 2) return 0;
     const int ch = blocks[0].out_features;
-    if (ch <= 8 || ch > 32) return 0;
+    if (ch < 8 || ch > 32) return 0;
     if (nblk == 2 && (blocks[1].out_features != ch || blocks[1].in_features != ch)) return 0;
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
     return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256 + plw_part_bytes(ch);
@@ -571,7 +572,10 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     const DevCemlp& C = plan.C;
     if (C.nblk < 1 || C.nblk > 2) return false;
     const int ch = C.b[0].O;
-    if (ch <= 8 || ch > 32 || !C.b[0].w1_sub) return false;
+    static const bool plw8 = getenv("CSMPN_PLW8") && atoi(getenv("CSMPN_PLW8"));   // 8 channels: wide kernels with one group
+    // 8 channels belong to cemlp_pl.hpp (4-5x faster there); the one-group wide kernels take them only on request or in
+    // deterministic mode (their parameter sums are atomic-free)
+    if ((ch <= 8 && !(ch == 8 && (plw8 || io.row_store))) || ch > 32 || !C.b[0].w1_sub) return false;
     if (C.nblk == 2 && (C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub)) return false;
     int na = 0;
     if (mode == MODE_EDGE) {
@@ -602,7 +606,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         int channels = 0, attr = 0;
         if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
             const long tiles = (io.rows + 3) / 4;          // one 4-row tile per workgroup iteration
-            const long cap_plw = bwd ? kPlwMaxGroups : 2 * kPlwMaxGroups;   // forward: two workgroups per CU where LDS allows
+            const long per_cu = 4 / ((channels + 7) / 8) > 0 ? 4 / ((channels + 7) / 8) : 1;   // workgroups of NG waves per CU at one wave per SIMD
+            const long cap_plw = (bwd ? kPlwMaxGroups : 2 * kPlwMaxGroups) * per_cu;   // forward: twice that where LDS allows
             const unsigned grid = (unsigned)(tiles < cap_plw ? tiles : cap_plw);
             const size_t tb = (id == ALG_N5 ? cemlp_plw_table_floats_n5(mode, channels, attr, plan.C.nblk)
                                             : cemlp_plw_table_floats_n5m(mode, channels, attr, plan.C.nblk)) * sizeof(float);
@@ -1065,6 +1070,7 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
     if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, N, plan))) return rc;
     const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     io.y = out; io.resid = residual ? h : nullptr; io.save = save_inputs;
+    io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // node stage: no row table, only atomic-free kernels qualify
     return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream, need_pack);
 }
 
@@ -1088,6 +1094,7 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     const bool need_pack = true;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
+    io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;
     return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream, need_pack);
 }
 

@@ -244,7 +244,10 @@ CSMPN_DEV float sqrt_pos(float x) {
     return __builtin_fmaf(__builtin_fmaf(-s, s, x), 0.5f * r, s);
 }
 #endif
-CSMPN_DEV float sigmoidf(float x) { return fast_rcp(1.0f + exp_neg(x)); }
+// the argument is clamped at -87: exp(87) is the last finite power before v_exp_f32 returns inf, and inf poisons
+// both refinement steps (inf * 0 in exp_neg, -inf * 0 in fast_rcp) - a gate whose pre-activation is below -88
+// (large indefinite quadratic forms: Cl(4,1), hub nodes) came out NaN instead of 0. sigmoid(-87) = 1.6e-38.
+CSMPN_DEV float sigmoidf(float x) { return fast_rcp(1.0f + exp_neg(__builtin_fmaxf(x, -87.0f))); }
 CSMPN_DEV f4 rcp4(f4 x) { return f4{fast_rcp(x.x), fast_rcp(x.y), fast_rcp(x.z), fast_rcp(x.w)}; }
 CSMPN_DEV f4 sigmoid4(f4 x) { return f4{sigmoidf(x.x), sigmoidf(x.y), sigmoidf(x.z), sigmoidf(x.w)}; }
 CSMPN_DEV f4 sqrt4(f4 x) { return f4{sqrt_pos(x.x), sqrt_pos(x.y), sqrt_pos(x.z), sqrt_pos(x.w)}; }

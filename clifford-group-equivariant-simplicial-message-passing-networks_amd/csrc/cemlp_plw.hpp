@@ -31,6 +31,7 @@ struct PlwCfg {
     static constexpr int D = ALG::D, DL = P::DL, GC = P::GC, G = ALG::G, NP = ALG::P, QP = P::QP, N = ALG::n;
     static constexpr int ROW = C * D;
     static_assert(C > 8 * (NG - 1) && C <= 8 * NG, "NG = ceil(C / 8)");
+    static constexpr int WG_PER_CU_BWD = 4 / NG_ > 0 ? 4 / NG_ : 1;   // one wave per SIMD in the backward
     static_assert(NA >= 0 && NA <= 8, "attribute channels fit one chunk");
     static_assert(NBLK == 1 || NBLK == 2, "one or two blocks");
     static_assert(MODE != MODE_PLAIN || NA > 0, "MODE_PLAIN: NA = input channels (one chunk)");
@@ -296,7 +297,7 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
 // ---------------------------------------------------------------------------------
 // forward kernel: two blocks of C channels. BWD kernels: see cemlp_plw_bwd below.
 template <class ALG, class CF>
-__global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 2 : 1) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 2 * CF::WG_PER_CU_BWD : CF::WG_PER_CU_BWD) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
 // backward -> input gradients (scatter / rows). Parameter gradients of block BLK.
 template <class ALG, class CF, int BLK>
-__global__ void __launch_bounds__(64 * CF::NG, 1) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * CF::NG, CF::WG_PER_CU_BWD) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);

@@ -61,8 +61,9 @@ extern "C" {
                                        (the reference runs under torch.use_deterministic_algorithms(True),
                                        engineer/utils/seed.py:30). Only the kernels whose parameter-gradient
                                        sums are atomic-free honour it: Cl(3,0) with 8 or 16 channels, and Cl(5,0) /
-                                       Cl(4,1) with 16 / 24 / 28 / 32 channels (two blocks, saved block inputs);
-                                       every other shape returns CSMPN_ERR_UNSUPPORTED. */
+                                       Cl(4,1) with 8 / 16 / 24 / 28 / 32 channels (two blocks, saved block inputs);
+                                       every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
+                                       csmpn_egcl_node_forward/backward, where it only selects such kernels. */
 
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */

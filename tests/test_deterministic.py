@@ -92,7 +92,9 @@ def _run_layer(pkg, C, seed, N=2000, E=20000, metric=(1.0, 1.0, 1.0)):
 
 @pytest.mark.parametrize("C,metric,N,E", [(8, (1.0, 1.0, 1.0), 2000, 20000), (16, (1.0, 1.0, 1.0), 2000, 20000),
                                           # the wide parity-lane kernels: the convex-hulls width, and Cl(4,1)
-                                          (28, (1.0,) * 5, 400, 4000), (16, (1.0, 1.0, 1.0, 1.0, -1.0), 300, 3000)])
+                                          (28, (1.0,) * 5, 400, 4000), (16, (1.0, 1.0, 1.0, 1.0, -1.0), 300, 3000),
+                                          # 8 channels of D = 32: routed to the one-group wide kernels in this mode
+                                          (8, (1.0, 1.0, 1.0, 1.0, -1.0), 500, 5000)])
 def test_bit_reproducible(pkg, det, C, metric, N, E):
     once = _run_layer(pkg, C, seed=11, N=N, E=E, metric=metric)
     a = once()
@@ -127,10 +129,10 @@ def test_parity_vs_oracle(pkg, det, metric, C, aggr, N, E):
 def test_unsupported_shape(pkg, monkeypatch):
     from csmpn_hip import native, ops
     alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0, 1.0, 1.0))
-    layer = pkg.EGCL(alg, 8, 8, 8, aggr="mean").to(dev())
+    layer = pkg.EGCL(alg, 12, 12, 12, aggr="mean").to(dev())   # no attributes, 12 channels: general kernels
     g = torch.Generator().manual_seed(1)
     ei = torch.randint(0, 20, (2, 100), generator=g).to(dev())
-    h = torch.randn(20, 8, 32, generator=g).to(dev())
+    h = torch.randn(20, 12, 32, generator=g).to(dev())
     want = layer(h, ei)
     ops.set_deterministic(True)
     try:

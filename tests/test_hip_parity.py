@@ -500,6 +500,41 @@ def test_edge_stage_additivity_full_size(pkg, metric, C, N, E):
         assert relmax((x + y).cpu().numpy(), f.cpu().numpy()) < tol, f"tensor {i}"
 
 
+@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0, 1.0, 1.0), 12), ((1.0, 1.0, 1.0, 1.0, -1.0), 8),
+                                      ((1.0,) * 5, 28)])
+def test_saturated_gates_stay_finite(pkg, metric, C):
+    """Gate pre-activations far below -88 (large inputs, negative MVSiLU slopes): sigmoid must saturate to 0 like the
+    reference's, not overflow - v_exp_f32 returns inf there and an unclamped Newton refinement turns it into NaN
+    (found on Cl(4,1) with a 1 250-edge hub). Every kernel family: row-per-lane, general, parity-lane, wide parity-lane."""
+    D = 1 << len(metric)
+    N, E = 60, 400
+    oa = O.Algebra(list(metric), torch.float64)
+    o32 = O.Algebra(list(metric), torch.float32)
+    h, ei, ea, na = O.synthetic_complex(o32, N, E, C, seed=3)
+    h = 40.0 * h                                         # quadratic invariants of order 1e4..1e5
+    gen = torch.Generator().manual_seed(4)
+    p = O.init_egcl_params(o32, C, C, C, 6, 3, gen=gen, randomize=True)
+    for k in p:                                          # negative slopes: pre-activations -> -1e4
+        if k.endswith(".1.a"):
+            p[k] = -p[k].abs() - 0.5
+    alg = pkg.CliffordAlgebra(tuple(metric))
+    layer = pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean")
+    sd = layer.state_dict()
+    sd.update(p)
+    layer.load_state_dict(sd, strict=True)
+    layer = layer.to(dev())
+    hd = h.to(dev()).requires_grad_(True)
+    y = layer(hd, ei.to(dev()), ea.to(dev()), na.to(dev()))
+    y.sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(hd.grad).all()
+    for prm in layer.parameters():
+        assert torch.isfinite(prm.grad).all()
+    y64 = O.egcl(oa, h.double(), ei, ea.double(), na.double(), {k: v.double() for k, v in p.items()}, aggr="mean")
+    y32 = O.egcl(o32, h, ei, ea, na, p, aggr="mean")
+    assert torch.isfinite(y64).all()
+    check("y", y.detach().cpu().numpy(), y64.numpy(), y32.numpy(), slack=10.0 if min(metric) < 0 else 4.0)
+
+
 def test_csr_build(pkg):
     from csmpn_hip import ops
     g = torch.Generator().manual_seed(3)
