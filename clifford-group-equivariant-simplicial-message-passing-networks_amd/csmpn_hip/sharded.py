@@ -168,9 +168,7 @@ class GraphedShardedStep:
             e1 = int(plan.csr.row_ptr[n_half].item())
             # the choice changes which collectives a rank issues (two half-size all-reduces or one
             # whole one): it must be the same on every rank - split only if EVERY shard straddles N/2
-            can = torch.tensor([1 if 0 < e1 < plan.csr.n_edges else 0], dtype=torch.int32, device=h.device)
-            dist.all_reduce(can, op=dist.ReduceOp.MIN, group=self.group)
-            if int(can.item()) == 1:
+            if agree_all(0 < e1 < plan.csr.n_edges, self.group, h.device):
                 self._split = (n_half, e1)
 
         def part1():
@@ -181,7 +179,9 @@ class GraphedShardedStep:
             spec.edge.bind(pe)
             agg = torch.zeros(h_.shape[0], spec.O, spec.edge.D, dtype=torch.float32, device=h_.device)
             saved = spec.edge.new_saved(plan.csr.n_edges, h_.device)
-            per_row = saved.numel() // plan.csr.n_edges
+            # floats of one saved block-1 input row (NOT numel / rows: the buffer may carry a backward scratch region
+            # behind the [rows, O, D] inputs, see csmpn_cemlp_saved_floats_per_row)
+            per_row = int(spec.edge.params[0].out_features) * spec.edge.D
             _, (ws, _s) = be.edge_forward(spec, ops.CsrSlice(plan.csr, 0, e1), h_, ea, pe, agg=agg,
                                           saved=saved[:e1 * per_row])
             return agg, (ws, saved), per_row
@@ -295,6 +295,16 @@ def _reduce_scatter_rows(part, full, group):
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         w, r = dist.get_world_size(group), dist.get_rank(group)
         part.copy_(full.chunk(w, dim=0)[r])
+
+
+def agree_all(local_ok: bool, group=None, device=None) -> bool:
+    """True iff the condition holds on EVERY rank (all-reduce MIN of a flag). For choices that change which
+    collectives a rank issues: they must come out the same everywhere, or the ranks post mismatched collectives."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(local_ok)
+    flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
 
 
 class DstPlan:

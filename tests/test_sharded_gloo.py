@@ -164,3 +164,40 @@ def test_dst_partitioned_matches_unsharded(aggr, world):
         assert res["cover"] == 0
         for k, v in res.items():
             assert v < 5e-5, (rank, k, v)
+
+
+def _worker_agree(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        # a target-sorted edge list cut into 3 contiguous shards: only the middle shard straddles N / 2, so only
+        # rank 1 could split its edge forward in two - the collective decision must be "nobody splits"
+        N, E = 30, 300
+        dst = torch.sort(torch.randint(0, N, (E,), generator=torch.Generator().manual_seed(0))).values
+        lo, hi = sharded.shard_bounds(E, world, rank)
+        mine = dst[lo:hi]
+        e1 = int((mine < N // 2).sum())
+        local_ok = 0 < e1 < mine.numel()
+        res = {"local": bool(local_ok), "all": sharded.agree_all(local_ok), "all_true": sharded.agree_all(True)}
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_split_decision_is_collective_world3():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_agree, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [results[r]["local"] for r in range(3)] == [False, True, False]   # the ranks disagree locally ...
+    assert all(results[r]["all"] is False for r in range(3))                 # ... and agree collectively
+    assert all(results[r]["all_true"] is True for r in range(3))
