@@ -90,7 +90,7 @@ def test_sharded_hip_matches_unsharded(metric, C):
             assert v < 2e-5, (rank, k, v)
 
 
-def _worker_dst(rank, world, port, q):
+def _worker_dst(rank, world, port, q, metric=(1.0, 1.0, 1.0), C=8):
     """Partitioning B with the HIP backend: nodes partitioned, edges by target."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -101,11 +101,11 @@ def _worker_dst(rank, world, port, q):
         from oracle import ref_path as O
         dev = torch.device("cuda:0")
         torch.manual_seed(0)
-        alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
-        layer = pkg.EGCL(alg, 8, 8, 8, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
+        alg = pkg.CliffordAlgebra(tuple(metric))
+        layer = pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
         N, E = 500, 7001
-        h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra([1.0, 1.0, 1.0]), N, E, 8, seed=1))
-        gout = torch.randn(N, 8, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+        h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=1))
+        gout = torch.randn(N, C, 1 << len(metric), generator=torch.Generator().manual_seed(2)).to(dev)
         part = sharded.DstPartitionedEGCL(layer)
         plan = part.plan(ei, N)
         eal = ea[plan.edge_ids].contiguous()
@@ -133,11 +133,12 @@ def _worker_dst(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dst_partitioned_hip_matches_unsharded():
+@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0,) * 5, 8), ((1.0,) * 5, 28)])
+def test_dst_partitioned_hip_matches_unsharded(metric, C):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_dst, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_dst, args=(r, 2, port, q, metric, C)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]
