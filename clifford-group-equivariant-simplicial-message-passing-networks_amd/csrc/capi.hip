@@ -509,7 +509,12 @@ size_t plw_part_bytes(int ch) {
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
     const size_t image = 8 * NG * (3 + 3 * 6 + 64) + 16;   // per-channel sums (CP x (3 + 3 G + P)), generous
     const size_t per_cu = 4 / NG > 0 ? 4 / NG : 1;
-    return ((nch0 + 2 * NG) * 12 * 64 * NG + image) * sizeof(float) * kPlwMaxGroups * per_cu + 256;
+    size_t bytes = ((nch0 + 2 * NG) * 12 * 64 * NG + image) * sizeof(float) * kPlwMaxGroups * per_cu + 256;
+    if (ch == 8) {   // the 8-channel parity-lane backward (cemlp_pl.hpp): one slice per wave, 4 waves x 256 workgroups
+        const size_t pl = (size_t)(8 * 768 + 2 * 640) * sizeof(float) * 4 * kPlMaxBwdGroups + 256;
+        bytes = pl > bytes ? pl : bytes;
+    }
+    return bytes;
 }
 size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 5 || nblk < 1 || nblk > 2) return 0;
@@ -560,7 +565,6 @@ bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     if (mode == MODE_NODE && (io.seg[0].ch != 8 || io.seg[1].ch != 8)) return false;
     if (mode != MODE_EDGE && mode != MODE_NODE) return false;
     if (bwd && !io.saved) return false;
-    if (io.row_store) return false;   // the deterministic mode is the row-per-lane kernels' (atomic-free parameter sums)
     *i0 = C.b[0].I;
     return id == ALG_N5 ? has_cemlp_pl_n5(mode, C.nblk, 8, *i0) : has_cemlp_pl_n5m(mode, C.nblk, 8, *i0);
 }
@@ -573,9 +577,8 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     if (C.nblk < 1 || C.nblk > 2) return false;
     const int ch = C.b[0].O;
     static const bool plw8 = getenv("CSMPN_PLW8") && atoi(getenv("CSMPN_PLW8"));   // 8 channels: wide kernels with one group
-    // 8 channels belong to cemlp_pl.hpp (4-5x faster there); the one-group wide kernels take them only on request or in
-    // deterministic mode (their parameter sums are atomic-free)
-    if ((ch <= 8 && !(ch == 8 && (plw8 || io.row_store))) || ch > 32 || !C.b[0].w1_sub) return false;
+    // 8 channels belong to cemlp_pl.hpp (4-5x faster there); the one-group wide kernels take them only on request
+    if ((ch <= 8 && !(ch == 8 && plw8)) || ch > 32 || !C.b[0].w1_sub) return false;
     if (C.nblk == 2 && (C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub)) return false;
     int na = 0;
     if (mode == MODE_EDGE) {
@@ -629,6 +632,11 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             const long cap = bwd ? kPlMaxBwdGroups : 512;  // one / two 4-wave workgroups per CU
             const long groups = (tiles + 3) / 4;
             const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            if (bwd) {   // per-wave slices of parameter-gradient sums: at the end of the workspace (as the wide kernels' region)
+                const size_t pb = plw_part_bytes(8);
+                if (!plan.workspace || plan.workspace_bytes < pb + 1024) return fail(CSMPN_ERR_INVALID, "workspace too small for the parity-lane backward");
+                io.plw_part = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb - 16) & ~(size_t)255));
+            }
             bool handled = false;
             static const bool debug_pl = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_pl) fprintf(stderr, "[csmpn] pl mode=%d bwd=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, i0, grid, io.rows);

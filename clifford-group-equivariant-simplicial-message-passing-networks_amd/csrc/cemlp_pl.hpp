@@ -123,11 +123,10 @@ struct PlLay {
     static constexpr int i_w(int k) { return i_an(k) + C * G; }
     static constexpr int img_blk(int k) { return C * Iof(k) * G + 2 * C * C * G + 3 * C + 3 * C * G + C * NP; }
     static constexpr int img_total = (i_W1(NBLK - 1) + img_blk(NBLK - 1) + 3) & ~3;
-    static constexpr int img_off = sc_off + kPlWaves * scratch;
     static constexpr int fwd_total = sc_off + kPlWaves * scratch;
     // backward: lane-private running sums [block][slot][thread]
     static constexpr int n_sums = 3 + 3 * GC + 2 * QP;
-    static constexpr int tot_off = img_off + img_total;
+    static constexpr int tot_off = sc_off + kPlWaves * scratch;
     static constexpr int tot_blk = n_sums * 64 * kPlWaves;
     static constexpr int bwd_total = tot_off + NBLK * tot_blk;
 };
@@ -679,62 +678,129 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
 }
 
 // ---------------------------------------------------------------------------------
-// end of a backward launch: this wave's sums -> the workgroup's LDS image (ds_add), reference layouts
-template <class ALG, class LY, int K>
-CSMPN_DEV void pl_image_w(float* img, const f4 (&acc)[PS<ALG>::GC], int ioff, int I, int ch, const PlGeo<ALG>& ge) {
-    constexpr int GC = PS<ALG>::GC, G = ALG::G;
-    const int cin = 8 * ch + ge.c;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int i = 4 * ge.q + v, o = i >> 1, so = i & 1;
-        if (so == ge.s && cin < I) {
-#pragma unroll
-            for (int k = 0; k < GC; ++k) atomicAdd(img + ioff + (o * I + cin) * G + ge.grade(k), acc[k][v]);
-        }
-    }
+// end of a backward launch: every WAVE writes its parameter-gradient sums to its own slice of a partial buffer in the
+// workspace - the MFMA tiles as they are ([tile][class][v][lane], coalesced), the per-channel sums after a fixed-order
+// sum over the 4 row quarters (one MFMA with A = 1 per value) - and pl_reduce_kernel adds the slices in a fixed order:
+// no atomics anywhere, the gradients are bit-reproducible.
+template <class LY>
+struct PlPart {
+    static constexpr int GC = LY::GC, G = LY::G, NP = LY::NP, C = LY::C, NCH0 = LY::nch(0);
+    static constexpr int n_tiles = NCH0 + 5;     // W1_0 chunks, WR_0, WL_0, W1_1, WR_1, WL_1
+    static constexpr int w_floats = n_tiles * GC * 4 * 64;
+    static constexpr int i_b1 = 0, i_bL = C, i_la = 2 * C, i_sa = 3 * C, i_sb = i_sa + C * G, i_an = i_sb + C * G,
+                         i_w = i_an + C * G, i_blk = i_w + C * NP;
+    static constexpr int slice = (w_floats + 2 * i_blk + 3) & ~3;
+};
+CSMPN_DEV float pl_quarter_sum(float v) {
+    const f4 r = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, splat(0.f), 0, 0, 0);   // D[i][j] = sum_k B[k][j]
+    return r.x;
 }
+template <class ALG>
+CSMPN_DEV void pl_store_tile(float* slice, int tile_idx, const f4 (&acc)[PS<ALG>::GC], int lane) {
+    constexpr int GC = PS<ALG>::GC;
+#pragma unroll
+    for (int k = 0; k < GC; ++k)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) slice[((tile_idx * GC + k) * 4 + v) * 64 + lane] = acc[k][v];
+}
+// per-channel sums of block K: quarter sums -> the wave's scratch image (single writer per entry) -> slice tail
 template <class ALG, class LY, int K>
-CSMPN_DEV void pl_image_small(float* img, const float* tot, const PlGeo<ALG>& ge) {
+CSMPN_DEV void pl_store_small(float* slice_tail, float* sc, const float* tot, const PlGeo<ALG>& ge) {
     using P = PS<ALG>;
     using SI = PlSumIdx<ALG>;
-    constexpr int GC = P::GC, G = ALG::G, NP = ALG::P;
+    using PP = PlPart<LY>;
+    constexpr int GC = P::GC, G = ALG::G, NP = ALG::P, C = LY::C;
+    constexpr int L_la2 = PP::i_blk;     // la per (channel, parity) behind the block image
     const int c = ge.c;
-    atomicAdd(img + LY::i_la(K) + c, tot[SI::la * kPlThreads]);
-    if (ge.s == 0) {
-        atomicAdd(img + LY::i_bL(K) + c, tot[SI::bL * kPlThreads]);
-        atomicAdd(img + LY::i_b1(K) + c, tot[SI::b1 * kPlThreads]);
+    const bool w0 = ge.q == 0;
+    tile_sync<VAR_WAVE>();
+    for (int e = ge.lane; e < PP::i_blk + 2 * C; e += 64) sc[e] = 0.f;
+    tile_sync<VAR_WAVE>();
+    {
+        const float la = pl_quarter_sum(tot[SI::la * kPlThreads]);
+        const float bL = pl_quarter_sum(tot[SI::bL * kPlThreads]);
+        const float b1 = pl_quarter_sum(tot[SI::b1 * kPlThreads]);
+        if (w0) {
+            sc[L_la2 + 2 * c + ge.s] = la;
+            if (ge.s == 0) { sc[PP::i_bL + c] = bL; sc[PP::i_b1 + c] = b1; }
+        }
     }
 #pragma unroll
     for (int k = 0; k < GC; ++k) {
         const int pg = c * G + ge.grade(k);
-        atomicAdd(img + LY::i_an(K) + pg, tot[(SI::an + k) * kPlThreads]);
-        atomicAdd(img + LY::i_sa(K) + pg, tot[(SI::sa + k) * kPlThreads]);
-        atomicAdd(img + LY::i_sb(K) + pg, tot[(SI::sb + k) * kPlThreads]);
+        const float an = pl_quarter_sum(tot[(SI::an + k) * kPlThreads]);
+        const float sa = pl_quarter_sum(tot[(SI::sa + k) * kPlThreads]);
+        const float sb = pl_quarter_sum(tot[(SI::sb + k) * kPlThreads]);
+        if (w0) { sc[PP::i_an + pg] = an; sc[PP::i_sa + pg] = sa; sc[PP::i_sb + pg] = sb; }
     }
     static_for<0, P::QP>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
-        atomicAdd(img + LY::i_w(K) + c * NP + (ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q]), tot[(SI::wA + q) * kPlThreads]);
-        atomicAdd(img + LY::i_w(K) + c * NP + (ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q]),
-                  tot[(SI::wB + q) * kPlThreads] * (ge.s ? 1.0f : float(P::t.I2)));
+        const float a = pl_quarter_sum(tot[(SI::wA + q) * kPlThreads]);
+        const float b = pl_quarter_sum(tot[(SI::wB + q) * kPlThreads]) * (ge.s ? 1.0f : float(P::t.I2));
+        if (w0) {
+            sc[PP::i_w + c * NP + (ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q])] = a;
+            sc[PP::i_w + c * NP + (ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q])] = b;
+        }
     });
+    tile_sync<VAR_WAVE>();
+    for (int e = ge.lane; e < PP::i_blk; e += 64) {
+        float v = sc[e];
+        if (e >= PP::i_la && e < PP::i_sa) v = sc[L_la2 + 2 * (e - PP::i_la)] + sc[L_la2 + 2 * (e - PP::i_la) + 1];
+        slice_tail[e] = v;
+    }
+    tile_sync<VAR_WAVE>();
 }
-template <class LY, int K>
-CSMPN_DEV void pl_flush_image(const float* img, const DevBlock& B, int tid) {
-    constexpr int C = LY::C, G = LY::G, NP = LY::NP, I = LY::Iof(K), NT = 64 * kPlWaves;
-    auto flush = [&](float* dst, int off, int n) {
-        if (dst)
-            for (int e = tid; e < n; e += NT) atomicAdd(dst + e, img[off + e]);
-    };
-    flush(B.gW1, LY::i_W1(K), C * I * G);
-    flush(B.gWR, LY::i_WR(K), C * C * G);
-    flush(B.gWL, LY::i_WL(K), C * C * G);
-    if (B.has_b1) flush(B.gb1, LY::i_b1(K), C);
-    flush(B.gbL, LY::i_bL(K), C);
-    flush(B.gla, LY::i_la(K), C);
-    flush(B.gsa, LY::i_sa(K), C * G);
-    flush(B.gsb, LY::i_sb(K), C * G);
-    flush(B.gan, LY::i_an(K), C * G);
-    flush(B.gw, LY::i_w(K), C * NP);
+// grads += sum over the waves' slices, fixed order; one thread per slice element (64 per workgroup x 4 slice subsets)
+template <class ALG, int NBLK, int I0>
+__global__ void __launch_bounds__(256) pl_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
+    using LY = PlLay<ALG, NBLK, I0>;
+    using PP = PlPart<LY>;
+    constexpr int GC = LY::GC, G = ALG::G, C = LY::C, NCH0 = PP::NCH0, NP = ALG::P;
+    __shared__ float red[4][64];
+    const int sub = threadIdx.x >> 6;
+    const long t = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+    float* dst = nullptr;
+    if (t < PP::w_floats) {
+        const int lane = (int)(t % 64), slot = (int)(t / 64);
+        const int v = slot & 3, k = (slot >> 2) % GC, tile_idx = (slot >> 2) / GC;
+        const int q = lane >> 4, n = lane & 15, c = n >> 1, s = n & 1;
+        const int i = 4 * q + v, o = i >> 1, so = i & 1;
+        int blk, table, ch;   // table: 0 W1, 1 WR, 2 WL
+        if (tile_idx < NCH0) { blk = 0; table = 0; ch = tile_idx; }
+        else if (tile_idx < NCH0 + 2) { blk = 0; table = 1 + (tile_idx - NCH0); ch = 0; }
+        else { blk = 1; table = tile_idx - NCH0 - 2; ch = 0; }
+        const int I = (blk == 0 && table == 0) ? I0 : C;
+        const int cin = 8 * ch + c;
+        const DevBlock& B = Cd.b[blk];
+        float* gW = table == 0 ? B.gW1 : (table == 1 ? B.gWR : B.gWL);
+        if (so == s && cin < I && gW) dst = gW + ((size_t)o * I + cin) * G + (s ? ALG::n - 2 * k : 2 * k);
+    } else if (t < PP::w_floats + 2 * PP::i_blk) {
+        const int e2 = (int)(t - PP::w_floats), blk = e2 / PP::i_blk, e = e2 % PP::i_blk;
+        const DevBlock& B = Cd.b[blk];
+        if (e < PP::i_bL) { if (B.has_b1 && B.gb1) dst = B.gb1 + e; }
+        else if (e < PP::i_la) { if (B.gbL) dst = B.gbL + (e - PP::i_bL); }
+        else if (e < PP::i_sa) { if (B.gla) dst = B.gla + (e - PP::i_la); }
+        else if (e < PP::i_sb) { if (B.gsa) dst = B.gsa + (e - PP::i_sa); }
+        else if (e < PP::i_an) { if (B.gsb) dst = B.gsb + (e - PP::i_sb); }
+        else if (e < PP::i_w) { if (B.gan) dst = B.gan + (e - PP::i_an); }
+        else { if (B.gw) dst = B.gw + (e - PP::i_w); }
+        (void)NP;
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (dst) {
+        const float* p = part + t;
+        int g = sub;
+        for (; g + 12 < nslices; g += 16) {
+            s0 += p[(size_t)g * PP::slice];
+            s1 += p[(size_t)(g + 4) * PP::slice];
+            s2 += p[(size_t)(g + 8) * PP::slice];
+            s3 += p[(size_t)(g + 12) * PP::slice];
+        }
+        for (; g < nslices; g += 4) s0 += p[(size_t)g * PP::slice];
+    }
+    red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sub == 0 && dst) *dst += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // staged rows -> global. The staging tile holds kPlRows rows of `ncol` floats (row stride rs).
@@ -807,7 +873,6 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? 1 : CSMPN_PL_FWD_WAVES) c
     const int wave = threadIdx.x >> 6;
     const PlGeo<ALG> ge(threadIdx.x & 63);
     float* sc = lds0 + LY::sc_off + wave * LY::scratch;
-    float* img = lds0 + LY::img_off;
     float* lds = lds0;
     {
         const int probe = pl_dpp_i<0x122>(ge.n);
@@ -815,7 +880,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? 1 : CSMPN_PL_FWD_WAVES) c
         pl_stage_block<LY, ALG, 0>(lds, Cd.b[0], threadIdx.x, dir);
         pl_stage_block<LY, ALG, 1>(lds, Cd.b[1], threadIdx.x, dir);
         if constexpr (BWD)
-            for (int e = threadIdx.x; e < LY::img_total + NBLK * LY::tot_blk; e += 64 * kPlWaves) img[e] = 0.f;   // image + sums
+            for (int e = threadIdx.x; e < NBLK * LY::tot_blk; e += 64 * kPlWaves) lds0[LY::tot_off + e] = 0.f;   // running sums
     }
     __syncthreads();
 
@@ -1049,17 +1114,16 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? 1 : CSMPN_PL_FWD_WAVES) c
     }
 
     if constexpr (BWD) {
-        static_for<0, NCH0>([&](auto chc) { pl_image_w<ALG, LY, 0>(img, aW1_0[decltype(chc)::value], LY::i_W1(0), I0, decltype(chc)::value, ge); });
-        pl_image_w<ALG, LY, 0>(img, aWR_0, LY::i_WR(0), C, 0, ge);
-        pl_image_w<ALG, LY, 0>(img, aWL_0, LY::i_WL(0), C, 0, ge);
-        pl_image_w<ALG, LY, 1>(img, aW1_1, LY::i_W1(1), C, 0, ge);
-        pl_image_w<ALG, LY, 1>(img, aWR_1, LY::i_WR(1), C, 0, ge);
-        pl_image_w<ALG, LY, 1>(img, aWL_1, LY::i_WL(1), C, 0, ge);
-        pl_image_small<ALG, LY, 0>(img, tot0, ge);
-        pl_image_small<ALG, LY, 1>(img, tot1, ge);
-        __syncthreads();
-        pl_flush_image<LY, 0>(img, Cd.b[0], threadIdx.x);
-        pl_flush_image<LY, 1>(img, Cd.b[1], threadIdx.x);
+        using PP = PlPart<LY>;
+        float* slice = io.plw_part + ((size_t)blockIdx.x * kPlWaves + wave) * PP::slice;
+        static_for<0, NCH0>([&](auto chc) { pl_store_tile<ALG>(slice, decltype(chc)::value, aW1_0[decltype(chc)::value], ge.lane); });
+        pl_store_tile<ALG>(slice, NCH0, aWR_0, ge.lane);
+        pl_store_tile<ALG>(slice, NCH0 + 1, aWL_0, ge.lane);
+        pl_store_tile<ALG>(slice, NCH0 + 2, aW1_1, ge.lane);
+        pl_store_tile<ALG>(slice, NCH0 + 3, aWR_1, ge.lane);
+        pl_store_tile<ALG>(slice, NCH0 + 4, aWL_1, ge.lane);
+        pl_store_small<ALG, LY, 0>(slice + PP::w_floats, sc, tot0, ge);
+        pl_store_small<ALG, LY, 1>(slice + PP::w_floats + PP::i_blk, sc, tot1, ge);
     }
 }
 
