@@ -8,10 +8,12 @@ sub-modules' parameters to the fused HIP kernels through the C-ABI
 (csmpn_hip.ops). They require float32 GPU tensors and raise otherwise: there is
 no CPU path in this package (the CPU restatement is oracle/, test-only).
 
-The five small layers keep a standalone forward for API compatibility (none of
-the reference's models calls MVSiLU / NormalizationLayer / SteerableGeometric-
-ProductLayer / MVLayerNorm outside a CEMLP); MVLinear, which the models do call
-on its own, is routed to the HIP path as a degenerate row program when possible.
+The five small layers keep a standalone forward (none of the reference's models
+calls MVSiLU / NormalizationLayer / SteerableGeometricProductLayer / MVLayerNorm
+outside a CEMLP): float32 [rows, channels, D] device tensors go through the
+standalone HIP entry points (csmpn_mvlinear_*, csmpn_mvsilu_*, csmpn_mvnorm_*,
+csmpn_mvlayernorm_*, csmpn_wgp_*); anything else (CPU tensors of the module
+construction / state_dict tests, extra middle dimensions) takes the host formulation.
 """
 import math
 
@@ -103,6 +105,8 @@ class MVSiLU(nn.Module):
 
     def forward(self, input):
         alg = self.algebra
+        if self.invariant == "mag2" and ops.small_layer_on_hip(alg, input, self.a, self.b):
+            return ops.mvsilu_apply(alg, input, self.a, self.b)      # csmpn_mvsilu_forward / _backward
         higher = alg.grades[1:]
         inv = alg.norms(input, grades=higher) if self.invariant == "norm" else alg.qs(input, grades=higher)
         inv = torch.cat([input[..., :1], *inv], dim=-1)
@@ -119,6 +123,8 @@ class NormalizationLayer(nn.Module):
 
     def forward(self, input):
         assert input.shape[1] == self.in_features
+        if ops.small_layer_on_hip(self.algebra, input, self.a):
+            return ops.mvnorm_apply(self.algebra, input, self.a)     # csmpn_mvnorm_forward / _backward
         nrm = torch.cat(self.algebra.norms(input), dim=-1)
         nrm = torch.sigmoid(self.a) * (nrm - 1) + 1
         return input / (nrm[..., _blade_grades(self.algebra, nrm.device)] + EPS)
@@ -132,6 +138,8 @@ class MVLayerNorm(nn.Module):
         self.a = nn.Parameter(torch.ones(1, channels))
 
     def forward(self, input):
+        if ops.small_layer_on_hip(self.algebra, input, self.a):
+            return ops.mvlayernorm_apply(self.algebra, input, self.a)   # csmpn_mvlayernorm_forward / _backward
         scale = self.algebra.norm(input)[..., :1].mean(dim=1, keepdim=True) + EPS
         return unsqueeze_like(self.a, scale, dim=2) * input / scale
 
@@ -167,7 +175,10 @@ class SteerableGeometricProductLayer(nn.Module):
 
     def forward(self, input):
         right = self.normalization(self.linear_right(input))
-        prod = torch.einsum("bni,nijk,bnk->bnj", input, self._get_weight(), right)
+        if ops.small_layer_on_hip(self.algebra, input, self.weight):
+            prod = ops.wgp_apply(self.algebra, input, right, self.weight)   # csmpn_wgp_forward / _backward
+        else:
+            prod = torch.einsum("bni,nijk,bnk->bnj", input, self._get_weight(), right)
         if self.include_first_order:
             return (self.linear_left(input) + prod) / math.sqrt(2)
         return prod

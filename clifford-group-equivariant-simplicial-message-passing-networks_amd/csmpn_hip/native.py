@@ -29,6 +29,14 @@ EXPORTS = (
     "csmpn_cemlp_backward",
     "csmpn_mvlinear_forward",
     "csmpn_mvlinear_backward",
+    "csmpn_mvsilu_forward",
+    "csmpn_mvsilu_backward",
+    "csmpn_mvnorm_forward",
+    "csmpn_mvnorm_backward",
+    "csmpn_mvlayernorm_forward",
+    "csmpn_mvlayernorm_backward",
+    "csmpn_wgp_forward",
+    "csmpn_wgp_backward",
     "csmpn_csr_workspace_bytes",
     "csmpn_csr_build",
     "csmpn_csr_source_order",
@@ -96,6 +104,14 @@ def _load():
     sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_mvlinear_forward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp])
     sig("csmpn_mvlinear_backward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp, vp, vp])
+    sig("csmpn_mvsilu_forward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, i32, vp, vp])
+    sig("csmpn_mvsilu_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp])
+    sig("csmpn_mvnorm_forward", C.c_int, [fp, C.c_int, vp, vp, i64, i32, vp, vp])
+    sig("csmpn_mvnorm_backward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, i32, vp, vp, vp])
+    sig("csmpn_mvlayernorm_forward", C.c_int, [fp, C.c_int, vp, vp, i64, i32, vp, vp])
+    sig("csmpn_mvlayernorm_backward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, i32, vp, vp, vp])
+    sig("csmpn_wgp_forward", C.c_int, [fp, C.c_int, vp, vp, vp, i64, i32, vp, vp])
+    sig("csmpn_wgp_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp])
     sig("csmpn_csr_workspace_bytes", sz, [i64, i64])
     sig("csmpn_csr_build", C.c_int, [vp, i64, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_csr_source_order", C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])

@@ -666,6 +666,151 @@ class _MVLinearFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+# --------------------------------------------------------------------------------- the small layers on their own
+
+_SMALL_LAUNCHES = 0
+
+
+def small_layer_launches() -> int:
+    """Launches of the standalone small-layer entry points so far (tests assert that the HIP path ran)."""
+    return _SMALL_LAUNCHES
+
+
+def _small_args(x, what, params):
+    _require_device(x, f"{what} input")
+    if x.dim() != 3:
+        raise RuntimeError(f"{what}: the HIP path takes [rows, channels, D] inputs, got {tuple(x.shape)}")
+    for t in params:
+        if t.device != x.device or t.dtype != torch.float32:
+            raise RuntimeError(f"{what} parameters must be float32 on {x.device}, got {t.dtype} on {t.device}")
+    return x.contiguous()
+
+
+def _count():
+    global _SMALL_LAUNCHES
+    _SMALL_LAUNCHES += 1
+
+
+class _MVSiLUFn(torch.autograd.Function):
+    """csmpn_mvsilu_* (cegnn_utils.py:53-83, invariant "mag2"); a, b [1, C, G]."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, x, a, b, metric):
+        x = _small_args(x, "MVSiLU", (a, b))
+        a2, b2 = a.contiguous(), b.contiguous()
+        y = torch.empty_like(x)
+        check(native.lib().csmpn_mvsilu_forward(native.metric_array(metric), len(metric), x.data_ptr(), a2.data_ptr(),
+                                                b2.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), _stream(x.device)))
+        _count()
+        ctx.save_for_backward(x, a2, b2)
+        ctx.metric = metric
+        return y
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, gy):
+        x, a, b = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx, ga, gb = torch.empty_like(x), torch.zeros_like(a), torch.zeros_like(b)
+        check(native.lib().csmpn_mvsilu_backward(native.metric_array(ctx.metric), len(ctx.metric), x.data_ptr(),
+                                                 a.data_ptr(), b.data_ptr(), gy.data_ptr(), x.shape[0], x.shape[1],
+                                                 gx.data_ptr(), ga.data_ptr(), gb.data_ptr(), _stream(x.device)))
+        _count()
+        return gx, ga, gb, None
+
+
+class _RowParamFn(torch.autograd.Function):
+    """NormalizationLayer (csmpn_mvnorm_*, a [C, G]) and MVLayerNorm (csmpn_mvlayernorm_*, a [1, C]): one
+    parameter tensor, same call shape."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, x, a, metric, which):
+        x = _small_args(x, which, (a,))
+        a2 = a.contiguous()
+        y = torch.empty_like(x)
+        fwd = getattr(native.lib(), f"csmpn_{which}_forward")
+        check(fwd(native.metric_array(metric), len(metric), x.data_ptr(), a2.data_ptr(), x.shape[0], x.shape[1],
+                  y.data_ptr(), _stream(x.device)))
+        _count()
+        ctx.save_for_backward(x, a2)
+        ctx.metric, ctx.which = metric, which
+        return y
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, gy):
+        x, a = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx, ga = torch.empty_like(x), torch.zeros_like(a)
+        bwd = getattr(native.lib(), f"csmpn_{ctx.which}_backward")
+        check(bwd(native.metric_array(ctx.metric), len(ctx.metric), x.data_ptr(), a.data_ptr(), gy.data_ptr(),
+                  x.shape[0], x.shape[1], gx.data_ptr(), ga.data_ptr(), _stream(x.device)))
+        _count()
+        return gx, ga, None, None
+
+
+class _WgpFn(torch.autograd.Function):
+    """The path-weighted geometric product of SteerableGeometricProductLayer (csmpn_wgp_*,
+    cegnn_utils.py:126-152): z, r [rows, C, D], weight [C, P]."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, z, r, weight, metric):
+        z = _small_args(z, "weighted geometric product", (r, weight))
+        r2, w2 = r.contiguous(), weight.contiguous()
+        if r2.shape != z.shape or w2.shape[0] != z.shape[1]:
+            raise RuntimeError(f"weighted geometric product: shapes {tuple(z.shape)}, {tuple(r2.shape)}, {tuple(w2.shape)}")
+        y = torch.empty_like(z)
+        check(native.lib().csmpn_wgp_forward(native.metric_array(metric), len(metric), z.data_ptr(), r2.data_ptr(),
+                                             w2.data_ptr(), z.shape[0], z.shape[1], y.data_ptr(), _stream(z.device)))
+        _count()
+        ctx.save_for_backward(z, r2, w2)
+        ctx.metric = metric
+        return y
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, gy):
+        z, r, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gz, gr, gw = torch.empty_like(z), torch.empty_like(r), torch.zeros_like(w)
+        check(native.lib().csmpn_wgp_backward(native.metric_array(ctx.metric), len(ctx.metric), z.data_ptr(), r.data_ptr(),
+                                              w.data_ptr(), gy.data_ptr(), z.shape[0], z.shape[1], gz.data_ptr(),
+                                              gr.data_ptr(), gw.data_ptr(), _stream(z.device)))
+        _count()
+        return gz, gr, gw, None
+
+
+def _metric_of(algebra):
+    mt = getattr(algebra, "metric_tuple", None)     # host copy: no device synchronisation per call
+    return tuple(float(m) for m in (mt if mt is not None else algebra.metric.tolist()))
+
+
+def small_layer_on_hip(algebra, x, *params) -> bool:
+    """True when a standalone small layer takes the HIP entry points: float32 [rows, C, D] device input, a
+    signature the kernels are compiled for, at most 256 channels, parameters on the same device."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[1] <= 256
+            and getattr(algebra, "hip_supported", False) and all(p.is_cuda for p in params))
+
+
+def mvsilu_apply(algebra, x, a, b):
+    return _MVSiLUFn.apply(x, a, b, _metric_of(algebra))
+
+
+def mvnorm_apply(algebra, x, a):
+    return _RowParamFn.apply(x, a, _metric_of(algebra), "mvnorm")
+
+
+def mvlayernorm_apply(algebra, x, a):
+    return _RowParamFn.apply(x, a, _metric_of(algebra), "mvlayernorm")
+
+
+def wgp_apply(algebra, z, r, weight):
+    return _WgpFn.apply(z, r, weight, _metric_of(algebra))
+
+
 def mvlinear_apply(x, weight, bias, n):
     return _MVLinearFn.apply(x, weight, bias, int(n))
 

@@ -433,23 +433,53 @@ struct RlRed {
         *reinterpret_cast<f4*>(sc + ge.r_w + (IDX % 8) * 260) = v;
         if constexpr (IDX % 8 == 7 || IDX == LY::n_red - 1) flush<IDX / 8>();
     }
+    // LDS byte address of a pointer into the dynamic LDS (the low half of the flat address)
+    static CSMPN_DEV unsigned lds_addr(const float* p) { return (unsigned)(unsigned long long)p; }
+    // four 16-byte LDS reads (byte offsets O0..O3 from address a), ALL in flight before the first use;
+    // the caller waits (s_waitcnt lgkmcnt(0) in its own asm statement, tied to the values). Written as asm:
+    // left to the scheduler, the register pressure of the backward makes it read, wait and add one value
+    // at a time (8 + 4 serial LDS round trips per flush, 10 flushes per tile).
+    template <int O0, int O1, int O2, int O3>
+    static CSMPN_DEV void lds_read4(unsigned a, f4& v0, f4& v1, f4& v2, f4& v3) {
+        asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                     "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                     : "v"(a), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
+                     : "memory");
+    }
     template <int CH>
     CSMPN_DEV void flush() {
         constexpr int NOG = GE::C / 4;
         float* w = sc + ge.r_w;
-        const float* rd = sc + ge.r_r;
-        f4 s = ld4(rd);
-        // the 8 source lanes of this lane's (value, channel group): NOG = 2: 8 consecutive lanes;
-        // NOG = 4: 4 rows of each of two DPP rows
-#pragma unroll
-        for (int k = 1; k < 8; ++k) s += ld4(rd + 4 * (NOG == 2 ? k : (k & 3) + 16 * (k >> 2)));
-        *reinterpret_cast<f4*>(w + 8 * 260) = s;
-        const float* r2 = sc + ge.r_r2;
-        f4 t = ld4(r2);
-#pragma unroll
-        for (int k = 1; k < 8 / NOG; ++k) t += ld4(r2 + 32 * NOG * k);
         float* a = tot + ge.r_t + CH * 256;
-        *reinterpret_cast<f4*>(a) = ld4(a) + t;
+        if constexpr (NOG == 2) {
+            // lane L sums value L & 7 over the 8 consecutive source lanes of its channel group, then over the 4
+            // DPP rows (256 floats apart), and adds the result to its running total. Batched reads (measured:
+            // S1 edge backward -2.5 %; the 16-channel kernels have no registers to spare for them, below)
+            const unsigned ar = lds_addr(sc + ge.r_r);
+            f4 v[8];
+            lds_read4<0, 16, 32, 48>(ar, v[0], v[1], v[2], v[3]);
+            lds_read4<64, 80, 96, 112>(ar, v[4], v[5], v[6], v[7]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+            const f4 s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            *reinterpret_cast<f4*>(w + 8 * 260) = s;
+            f4 u[4], old;
+            lds_read4<0, 256, 512, 768>(lds_addr(sc + ge.r_r2), u[0], u[1], u[2], u[3]);
+            asm volatile("ds_read_b128 %0, %5\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : "v"(lds_addr(a)) : "memory");
+            *reinterpret_cast<f4*>(a) = old + ((u[0] + u[1]) + (u[2] + u[3]));
+        } else {
+            // 4 rows of each of two DPP rows, then the two DPP-row pairs (128 floats apart)
+            const float* rd = sc + ge.r_r;
+            f4 s = ld4(rd);
+#pragma unroll
+            for (int k = 1; k < 8; ++k) s += ld4(rd + 4 * ((k & 3) + 16 * (k >> 2)));
+            *reinterpret_cast<f4*>(w + 8 * 260) = s;
+            const float* r2 = sc + ge.r_r2;
+            f4 t = ld4(r2);
+#pragma unroll
+            for (int k = 1; k < 8 / NOG; ++k) t += ld4(r2 + 32 * NOG * k);
+            *reinterpret_cast<f4*>(a) = ld4(a) + t;
+        }
     }
 };
 // reduction-order index -> (offset of the parameter's first element inside the small block, stride

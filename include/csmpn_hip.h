@@ -154,6 +154,37 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
                             int32_t in_features, int32_t out_features, int32_t subspaces, float* gx, float* g_weight,
                             float* g_bias, void* stream);
 
+/* The four small layers on their own (inside a CEMLP they are fused into the row programs; no
+ * reference model calls them alone - these entry points give the nn.Modules a device forward /
+ * backward). Rows are [rows, channels, D] float32, D = 2^n; metric entries +-1, n = 2..5 (the
+ * signatures csmpn_metric_supported accepts); channels <= 256. Backward: gx overwritten, parameter
+ * gradients ACCUMULATED (+=, float atomics: one per parameter and workgroup).
+ *   MVSiLU, invariant "mag2" (cegnn_utils.py:53-83): a, b [channels, n+1]
+ *     y_d = sigmoid(a[c,g] u_g + b[c,g]) x_d,  g = grade(d), u_0 = x_0, u_g = q_g(x) for g > 0
+ *   NormalizationLayer (cegnn_utils.py:34-51): a [channels, n+1]
+ *     y_d = x_d / (sigmoid(a[c,g]) (|x|_g - 1) + 1 + 1e-6),  |x|_g = (q_g(x)^2 + 1e-16)^(1/4)
+ *   MVLayerNorm (cegnn_utils.py:86-96): a [channels]
+ *     y[c] = a[c] x[c] / (mean_c |x[c]| + 1e-6),  |x| over all blades
+ *   weighted geometric product of SteerableGeometricProductLayer (cegnn_utils.py:126-152):
+ *     weight [channels, P] (P = number of grade paths, cliffordalgebra.py:238-252)
+ *     y_j = sum_{(i,k)->j} sign(i,k) weight[c, path(grade i, grade j, grade k)] z_i r_k */
+int csmpn_mvsilu_forward(const float* metric_host, int n, const float* x, const float* a, const float* b, int64_t rows,
+                         int32_t channels, float* y, void* stream);
+int csmpn_mvsilu_backward(const float* metric_host, int n, const float* x, const float* a, const float* b, const float* gy,
+                          int64_t rows, int32_t channels, float* gx, float* g_a, float* g_b, void* stream);
+int csmpn_mvnorm_forward(const float* metric_host, int n, const float* x, const float* a, int64_t rows, int32_t channels,
+                         float* y, void* stream);
+int csmpn_mvnorm_backward(const float* metric_host, int n, const float* x, const float* a, const float* gy, int64_t rows,
+                          int32_t channels, float* gx, float* g_a, void* stream);
+int csmpn_mvlayernorm_forward(const float* metric_host, int n, const float* x, const float* a, int64_t rows,
+                              int32_t channels, float* y, void* stream);
+int csmpn_mvlayernorm_backward(const float* metric_host, int n, const float* x, const float* a, const float* gy,
+                               int64_t rows, int32_t channels, float* gx, float* g_a, void* stream);
+int csmpn_wgp_forward(const float* metric_host, int n, const float* z, const float* r, const float* weight, int64_t rows,
+                      int32_t channels, float* y, void* stream);
+int csmpn_wgp_backward(const float* metric_host, int n, const float* z, const float* r, const float* weight,
+                       const float* gy, int64_t rows, int32_t channels, float* gz, float* gr, float* g_weight, void* stream);
+
 /* One-time per complex: sort the E directed adjacencies by target (stable radix sort).
  * edge_index is the reference's [2,E] int64 (row 0 = source j, row 1 = target i).
  * Outputs (device): perm[E] (sorted position -> original edge id), src_sorted[E],

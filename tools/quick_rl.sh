@@ -14,5 +14,5 @@ if [ -n "$STAMPS" ]; then EXTRA="$EXTRA -DCSMPN_STAMPS"; OUT=../csmpn_hip/libcsm
 hipcc $FLAGS $EXTRA $VF -c k_rl_n3.hip -o $RLO &
 if [ "$1" = "capi" ]; then hipcc $FLAGS -c capi.hip -o $B/capi.o & hipcc $FLAGS -c csr.hip -o $B/csr.o & fi
 wait
-hipcc -shared -fPIC --offload-arch=gfx950 $B/capi.o $B/csr.o $B/k_n2.o $B/k_n3.o $B/k_n4.o $B/k_n4m.o $B/k_n5.o $B/k_n5m.o $B/glue.o $B/k_pl_n5.o $B/k_pl_n5m.o $B/k_plw_n5.o $B/k_plw_n5m.o $RLO -o $OUT
+hipcc -shared -fPIC --offload-arch=gfx950 $B/capi.o $B/csr.o $B/k_n2.o $B/k_n3.o $B/k_n4.o $B/k_n4m.o $B/k_n5.o $B/k_n5m.o $B/glue.o $B/layers.o $B/k_pl_n5.o $B/k_pl_n5m.o $B/k_plw_n5.o $B/k_plw_n5m.o $RLO -o $OUT
 echo built $OUT
