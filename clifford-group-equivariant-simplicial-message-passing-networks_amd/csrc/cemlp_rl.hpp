@@ -229,40 +229,50 @@ __device__ void rl_stage_store(const DevBlock& B, float* lds, int tid) {
     constexpr int total = LY::store_total(K), nW1 = C * WSa, nW = nW1 + 2 * C * WSC;
     constexpr int NIT = (total + 64 * kRlWaves - 1) / (64 * kRlWaves);
     float* st = lds + LY::st_off(K);
+    // the parameter pointers first, as uniform values (scalar loads of the kernel arguments): selected per
+    // thread by ADDRESS inside the branches below, the compiler fetched them with vector loads, one
+    // dependent round trip in front of every value (2 NIT serialised memory latencies per block)
+    const float *pW1 = B.W1, *pWR = B.WR, *pWL = B.WL, *pb1 = B.b1, *pbL = B.bL, *pla = B.la, *psa = B.sa, *psb = B.sb,
+                *pan = B.an, *pw = B.w;
+    const bool has_b1 = B.has_b1 != 0;
     float v[NIT];
+    const float* src[NIT];
+    bool sig[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 64 * kRlWaves;
-        const float* src = nullptr;
-        bool sig = false;
+        src[it] = nullptr;
+        sig[it] = false;
         if (e < nW1) {
             const int o = e / WSa, r = e - o * WSa, c = r >> 2, g = r & 3;
-            if (c < I && g < G) src = B.W1 + (o * I + c) * G + g;
+            if (c < I && g < G) src[it] = pW1 + (o * I + c) * G + g;
         } else if (e < nW) {
             const int f0 = e - nW1, which = f0 / (C * WSC), f = f0 - which * (C * WSC);
             const int o = f / WSC, r = f - o * WSC, c = r >> 2, g = r & 3;
-            if (c < C && g < G) src = (which == 0 ? B.WR : B.WL) + (o * C + c) * G + g;
+            if (c < C && g < G) src[it] = (which == 0 ? pWR : pWL) + (o * C + c) * G + g;
         } else if (e < total) {
             int f = e - nW;
-            if (f < C) { if (B.has_b1) src = B.b1 + f; }
-            else if ((f -= C) < C) src = B.bL + f;
-            else if ((f -= C) < C) src = B.la + f;
+            if (f < C) { if (has_b1) src[it] = pb1 + f; }
+            else if ((f -= C) < C) src[it] = pbL + f;
+            else if ((f -= C) < C) src[it] = pla + f;
             else if ((f -= C) < 3 * C * G) {
                 const int which = f / (C * G), r = f - which * C * G, g = r / C, o = r - g * C;
-                src = (which == 0 ? B.sa : (which == 1 ? B.sb : B.an)) + o * G + g;
-                sig = which == 2;
+                src[it] = (which == 0 ? psa : (which == 1 ? psb : pan)) + o * G + g;
+                sig[it] = which == 2;
             } else {
                 f -= 3 * C * G;
                 const int p = f / C, o = f - p * C;
-                src = B.w + o * P + p;
+                src[it] = pw + o * P + p;
             }
         }
-        v[it] = src ? *src : 0.f;
-        if (sig) v[it] = sigmoidf(v[it]);
     }
+    // all loads of the thread in flight together
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it] = src[it] ? *src[it] : 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * 64 * kRlWaves;
+        if (sig[it]) v[it] = sigmoidf(v[it]);
         if (e < total) st[e] = v[it];
     }
 }
@@ -316,6 +326,40 @@ __global__ void __launch_bounds__(256) rl_reduce_kernel(const DevCemlp C_arg, co
 }
 
 // ---------------------------------------------------------------------------------
+// Explicitly ordered LDS reads (asm): under the register pressure of the backward kernels the scheduler
+// issues an LDS read right in front of its first use and waits for it with nothing in between; these
+// helpers put four 16-byte reads in flight and let the caller decide where to wait.
+CSMPN_DEV unsigned rl_lds_addr(const float* p) { return (unsigned)(unsigned long long)p; }   // LDS byte address
+template <int O0, int O1, int O2, int O3>
+CSMPN_DEV void rl_lds_read4(unsigned a, f4 (&w)[4]) {   // byte offsets from a; read-only data (the weight store)
+    asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
+                 "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+                 : "v"(a), "n"(O0), "n"(O1), "n"(O2), "n"(O3));
+}
+CSMPN_DEV void rl_lds_wait(f4 (&w)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
+}
+// groups of four weight vectors, software-pipelined by hand: group g + 1 is read while the MFMAs of group g
+// run. read(g, w) issues the reads of group g, use(g, w) consumes them.
+template <int NG, class Read, class Use>
+CSMPN_DEV void rl_weight_pipeline(Read&& read, Use&& use) {
+    f4 w[4];
+    read(IC<0>{}, w);
+    rl_lds_wait(w);
+    static_for<0, NG>([&](auto g) {
+        f4 wn[4];
+        if constexpr (g + 1 < NG) read(IC<g + 1>{}, wn);
+        use(g, w);
+        if constexpr (g + 1 < NG) {
+            rl_lds_wait(wn);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = wn[i];
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------
 // dense channel mixing on the 4x4x1 MFMA. acc = the lane's 4 output channels. WOFF = LDS float
 // offset of the weight matrix (compile time: an instruction immediate).
 
@@ -326,6 +370,20 @@ template <class ALG, int WOFF, int C0, int NCH, class GE>
 CSMPN_DEV void rl_linear_x(f4 (&acc)[ALG::D], const float (&X)[NCH][ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D;
     const float* wp = lds + ge.a_x;
+    if constexpr (GE::C == 8) {
+        constexpr int NG = (NCH + 3) / 4;
+        const unsigned a = rl_lds_addr(wp);
+        auto off = [](int g, int i) { const int c = 4 * g + i; return 4 * (WOFF + 4 * (C0 + (c < NCH ? c : NCH - 1))); };
+        rl_weight_pipeline<NG>(
+            [&](auto g, f4 (&w)[4]) { rl_lds_read4<off(g, 0), off(g, 1), off(g, 2), off(g, 3)>(a, w); },
+            [&](auto g, const f4 (&w)[4]) {
+                static_for<0, 4>([&](auto i) {
+                    constexpr int c = 4 * g + i;
+                    if constexpr (c < NCH) static_for<0, D>([&](auto d) { acc[d] = mfma4(w[i][ALG::grade(d)], X[c][d], acc[d]); });
+                });
+            });
+        return;
+    }
     static_for<0, NCH>([&](auto c) {
         const f4 w = ld4(wp + (WOFF + 4 * (C0 + c)));
         static_for<0, D>([&](auto d) { acc[d] = mfma4(w[ALG::grade(d)], X[c][d], acc[d]); });
@@ -336,6 +394,18 @@ CSMPN_DEV void rl_linear_x(f4 (&acc)[ALG::D], const float (&X)[NCH][ALG::D], con
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_d(f4 (&acc)[ALG::D], const f4 (&T)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D;
+    if constexpr (NOG == 2) {
+        rl_weight_pipeline<NOG>(
+            [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * WOFF + 16, 4 * WOFF + 32, 4 * WOFF + 48>(rl_lds_addr(lds + ge.a_f[k]), w); },
+            [&](auto k, const f4 (&w)[4]) {
+                static_for<0, 4>([&](auto cl) {
+                    static_for<0, D>([&](auto d) {
+                        acc[d] = mfma4(w[cl][ALG::grade(d)], rl_piece<NOG, k>(T[d][int(cl)]), acc[d]);
+                    });
+                });
+            });
+        return;
+    }
     static_for<0, NOG>([&](auto k) {
         const float* wp = lds + ge.a_f[k];
         static_for<0, 4>([&](auto cl) {
@@ -351,6 +421,18 @@ CSMPN_DEV void rl_linear_d(f4 (&acc)[ALG::D], const f4 (&T)[ALG::D], const float
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D, WS = GE::WSC;
+    if constexpr (NOG == 2) {
+        rl_weight_pipeline<NOG>(
+            [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + ge.a_t[k]), w); },
+            [&](auto k, const f4 (&w)[4]) {
+                static_for<0, 4>([&](auto ol) {
+                    static_for<0, D>([&](auto d) {
+                        gx[d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[d]);
+                    });
+                });
+            });
+        return;
+    }
     static_for<0, NOG>([&](auto k) {
         const float* wp = lds + ge.a_t[k];
         static_for<0, 4>([&](auto ol) {
@@ -368,6 +450,22 @@ CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const flo
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_xt(f4 (&gx)[GE::NGL0][ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D, WS = GE::WS1;
+    if constexpr (NOG == 2) {
+        rl_weight_pipeline<GE::NGL0 * NOG>(
+            [&](auto g, f4 (&w)[4]) {
+                constexpr int t = g / NOG, k = g % NOG;
+                rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + (ge.a_ts[k] + ge.c_t[t])), w);
+            },
+            [&](auto g, const f4 (&w)[4]) {
+                constexpr int t = g / NOG, k = g % NOG;
+                static_for<0, 4>([&](auto ol) {
+                    static_for<0, D>([&](auto d) {
+                        gx[t][d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[t][d]);
+                    });
+                });
+            });
+        return;
+    }
     static_for<0, GE::NGL0>([&](auto t) {
         static_for<0, NOG>([&](auto k) {
             const float* wp = lds + (ge.a_ts[k] + ge.c_t[t]);
@@ -624,9 +722,12 @@ CSMPN_DEV void rl_wgrad(float* sc, const GE& ge, const int (&rb)[NT], f4 (&acc)[
 // parameters, accRL: linear_right | linear_left weight tiles), leaves d/d(MVLinear output) in gy.
 // The MVLinear weight gradient and the transposed MVLinear are the caller's (they need the
 // block's input again).
-template <class ALG, int NOG, int K, class GE>
+// early_loads(): called in front of the last phase (MVSiLU backward); the caller issues there the global loads
+// its next step needs (the block's input for the MVLinear weight gradient), so that their latency passes
+// under that phase instead of in front of the gradient loop.
+template <class ALG, int NOG, int K, class GE, class Early>
 CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFwd<ALG>& S, const f4 (&gout)[ALG::D],
-                                 f4 (&gy)[ALG::D], float* tot, f4 (&accRL)[GE::LY::MA_RL][1][ALG::G]) {
+                                 f4 (&gy)[ALG::D], float* tot, f4 (&accRL)[GE::LY::MA_RL][1][ALG::G], Early&& early_loads) {
     using LY = typename GE::LY;
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P, C = 4 * NOG, RS = GE::RS;
     using RM = RlRedMap<LY>;
@@ -744,6 +845,7 @@ CSMPN_DEV void rl_block_backward(float* lds, float* sc, const GE& ge, const RlFw
     }
     ge.stamp(13);
     CSMPN_PHASE();
+    early_loads();
     // ---- MVSiLU backward -> gy
     static_for<0, G>([&](auto g) {
         constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
@@ -849,12 +951,18 @@ CSMPN_DEV void rl_partials_image(float* img, const GE& ge, const f4 (&accW1)[1][
 // per-lane row access (16-byte pieces)
 
 // X[c0 .. c0+NCH) <- NCH*D contiguous floats at p
-template <class ALG, int NCH, int I>
+// PIN: the loads are issued HERE (an empty asm statement takes their results): the scheduler otherwise
+// moves them down between the consumers of earlier loads and each one is waited for on its own
+template <class ALG, int NCH, int I, bool PIN = false>
 CSMPN_DEV void rl_load_channels(float (&X)[I][ALG::D], int c0, const float* p) {
     constexpr int D = ALG::D, NQ = NCH * D / 4;
     f4 v[NQ];
 #pragma unroll
     for (int e = 0; e < NQ; ++e) v[e] = ld4(p + 4 * e);
+    if constexpr (PIN) {
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) asm volatile("" : "+v"(v[e]));
+    }
     static_for<0, NQ>([&](auto e) {
         static_for<0, 4>([&](auto k) {
             constexpr int f = 4 * e + k;
@@ -1043,6 +1151,36 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
         // lane of a row loads all of them: the NOG lanes issue the same addresses in one instruction)
         auto mvlinear0 = [&](f4 (&y)[D]) {
             constexpr int W1 = LY::o_W1(0);
+            if constexpr (NOG == 2 && MODE != MODE_PLAIN) {
+                // 8-channel layers: ALL of the row's inputs are requested before the first one is used (they
+                // fit in registers; the attribute loads are pinned to the request point). Chunk by chunk, the
+                // attribute loads were issued between the MFMAs of the first chunk and waited for one at a time.
+                constexpr int NAA = NA > 0 ? NA : 1;
+                float X[C][D], Y[C][D], A[NAA][D];
+                if constexpr (MODE == MODE_EDGE) {
+                    rl_load_channels<ALG, C>(X, 0, io.seg[0].a + (size_t)i_dst * ROW);
+                    rl_load_channels<ALG, C>(Y, 0, io.seg[0].b + (size_t)i_src * ROW);
+                    if constexpr (NA > 0) rl_load_channels<ALG, NA, NAA, true>(A, 0, io.seg[1].a + (size_t)i_perm * (NA * D));
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int d = 0; d < D; ++d) X[c][d] -= Y[c][d];
+                    rl_linear_x<ALG, W1, 0, C>(y, X, lds, ge);
+                    if constexpr (NA > 0) rl_linear_x<ALG, W1, C, NA>(y, A, lds, ge);
+                } else {
+                    rl_load_channels<ALG, C>(X, 0, io.seg[0].a + (size_t)lrow * ROW);
+                    rl_load_channels<ALG, C>(Y, 0, io.seg[1].a + (size_t)lrow * ROW);
+                    if constexpr (NA > 0) rl_load_channels<ALG, NA, NAA, true>(A, 0, io.seg[2].a + (size_t)lrow * (NA * D));
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+#pragma unroll
+                        for (int d = 0; d < D; ++d) Y[c][d] *= scale;
+                    rl_linear_x<ALG, W1, 0, C>(y, X, lds, ge);
+                    rl_linear_x<ALG, W1, C, C>(y, Y, lds, ge);
+                    if constexpr (NA > 0) rl_linear_x<ALG, W1, 2 * C, NA>(y, A, lds, ge);
+                }
+                return;
+            }
             auto chunks = [&](auto c0, auto n_total, const float* pa, const float* pb, float mul) {
                 // input channels c0 .. c0 + n_total from the contiguous row at pa (minus the row at pb)
                 static_for<0, (decltype(n_total)::value + 7) / 8>([&](auto q8) {
@@ -1077,31 +1215,61 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 chunks(IC<0>{}, IC<I0>{}, io.seg[0].a + (size_t)lrow * (I0 * D), nullptr, 1.0f);
             }
         };
-        // blade d of the input channels og, og + NOG, ... of this lane's row -> the B slice of the
-        // MVLinear weight gradient (scalar loads of rows the forward has just gathered: cache hits)
-        auto write_input_slice = [&](auto d, float* sB) {
-            float* p = sB + (ge.og * RS + ge.r);
-            static_for<0, (I0 + NOG - 1) / NOG>([&](auto t) {
+        // The B slices of block 0's MVLinear weight gradient: blade d of the input channels og, og + NOG, ...
+        // of this lane's row. The row is gathered again (cache hits: the forward recompute has just read it),
+        // ALL pieces in flight at once: issued blade by blade inside the gradient loop, the compiler waited
+        // for seven groups of loads one after the other.
+        constexpr int NT_IN = (I0 + NOG - 1) / NOG, DQ = D / 4;
+        // 8-channel kernels: the re-gather is issued in front of the last phase of the block backward. (Not for
+        // 16 channels: the register allocation of that variant crashes clang 22's AGPR-copy rewrite pass.)
+        constexpr bool kEarly = NOG == 2;
+        auto load_input_pieces = [&](f4 (&xin)[NT_IN][DQ]) {
+            constexpr int NTC = MODE == MODE_EDGE ? C / NOG : 1;
+            f4 ysrc[NTC][DQ];
+            static_for<0, NT_IN>([&](auto t) {
                 constexpr int cbase = NOG * t;          // segments start at multiples of NOG: one segment per t
-                float v;
+                const float* pa;
                 if constexpr (MODE == MODE_EDGE) {
-                    if constexpr (cbase < C)
-                        v = io.seg[0].a[(size_t)i_dst * ROW + (cbase + ge.og) * D + d] - io.seg[0].b[(size_t)i_src * ROW + (cbase + ge.og) * D + d];
-                    else {
+                    if constexpr (cbase < C) {
+                        pa = io.seg[0].a + (size_t)i_dst * ROW + (cbase + ge.og) * D;
+                        const float* pb = io.seg[0].b + (size_t)i_src * ROW + (cbase + ge.og) * D;
+#pragma unroll
+                        for (int q = 0; q < DQ; ++q) ysrc[t][q] = ld4(pb + 4 * q);
+                    } else {
                         const int ca = cbase - C + ge.og;
-                        v = io.seg[1].a[(size_t)i_perm * (NA * D) + (ca < NA ? ca : NA - 1) * D + d];
+                        pa = io.seg[1].a + (size_t)i_perm * (NA * D) + (ca < NA ? ca : NA - 1) * D;
                     }
                 } else if constexpr (MODE == MODE_NODE) {
-                    if constexpr (cbase < C) v = io.seg[0].a[(size_t)lrow * ROW + (cbase + ge.og) * D + d];
-                    else if constexpr (cbase < 2 * C) v = io.seg[1].a[(size_t)lrow * ROW + (cbase - C + ge.og) * D + d] * scale;
+                    if constexpr (cbase < C) pa = io.seg[0].a + (size_t)lrow * ROW + (cbase + ge.og) * D;
+                    else if constexpr (cbase < 2 * C) pa = io.seg[1].a + (size_t)lrow * ROW + (cbase - C + ge.og) * D;
                     else {
                         const int ca = cbase - 2 * C + ge.og;
-                        v = io.seg[2].a[(size_t)lrow * (NA * D) + (ca < NA ? ca : NA - 1) * D + d];
+                        pa = io.seg[2].a + (size_t)lrow * (NA * D) + (ca < NA ? ca : NA - 1) * D;
                     }
                 } else {
                     const int ca = cbase + ge.og;
-                    v = io.seg[0].a[(size_t)lrow * (I0 * D) + (ca < I0 ? ca : I0 - 1) * D + d];
+                    pa = io.seg[0].a + (size_t)lrow * (I0 * D) + (ca < I0 ? ca : I0 - 1) * D;
                 }
+#pragma unroll
+                for (int q = 0; q < DQ; ++q) xin[t][q] = ld4(pa + 4 * q);
+            });
+            static_for<0, NT_IN>([&](auto t) {
+                constexpr int cbase = NOG * t;
+                if constexpr (MODE == MODE_EDGE && cbase < C) {
+#pragma unroll
+                    for (int q = 0; q < DQ; ++q) xin[t][q] -= ysrc[t][q];
+                }
+                if constexpr (MODE == MODE_NODE && cbase >= C && cbase < 2 * C) {
+#pragma unroll
+                    for (int q = 0; q < DQ; ++q) xin[t][q] *= scale;
+                }
+            });
+        };
+        auto write_input_slice = [&](const f4 (&xin)[NT_IN][DQ], auto d, float* sB) {
+            float* p = sB + (ge.og * RS + ge.r);
+            static_for<0, NT_IN>([&](auto t) {
+                constexpr int cbase = NOG * t;
+                const float v = xin[t][int(d) / 4][int(d) % 4];
                 if constexpr (cbase + NOG <= I0) p[cbase * RS] = v;
                 else if (cbase + ge.og < I0) p[cbase * RS] = v;
             });
@@ -1171,17 +1339,24 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 for (int d = 0; d < D; ++d) in1[d] = in1_n[d];
                 ge.stamp(1);
                 f4 gy[D];
+                f4 in1b[D];   // the block input, loaded again: 4*D registers less across most of the block backward
                 {
                     RlFwd<ALG> S;
                     f4 unused[D];
                     forward1(in1, S, unused);
-                    rl_block_backward<ALG, NOG, 1>(lds, sc, ge, S, gout, gy, tot_1, accRL_1);
+                    rl_block_backward<ALG, NOG, 1>(lds, sc, ge, S, gout, gy, tot_1, accRL_1, [&] {
+                        if constexpr (kEarly) {
+                            asm volatile("" ::: "memory");
+                            rl_load_t<ALG>(in1b, io.saved + (size_t)lrow * ROW + ge.og * PIECE);
+                        }
+                    });
                 }
                 CSMPN_PHASE();
                 {
-                    f4 in1b[D];   // loaded again: 4*D registers less across the block backward
-                    asm volatile("" ::: "memory");
-                    rl_load_t<ALG>(in1b, io.saved + (size_t)lrow * ROW + ge.og * PIECE);
+                    if constexpr (!kEarly) {
+                        asm volatile("" ::: "memory");
+                        rl_load_t<ALG>(in1b, io.saved + (size_t)lrow * ROW + ge.og * PIECE);
+                    }
                     rl_w1_grad<ALG, NOG, 1>(sc, ge, gy, accW1_1, [&](auto d, float* sB) {
                         float* p = sB + ge.s_w;
 #pragma unroll
@@ -1199,14 +1374,16 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
             f4 gx[NGL][D];
             {
                 f4 gy[D];
+                f4 xin[NT_IN][DQ];
                 {
                     RlFwd<ALG> S;
                     f4 unused[D];
                     forward0(S, unused);
-                    rl_block_backward<ALG, NOG, 0>(lds, sc, ge, S, gout, gy, tot_0, accRL_0);
+                    rl_block_backward<ALG, NOG, 0>(lds, sc, ge, S, gout, gy, tot_0, accRL_0, [&] { if constexpr (kEarly) load_input_pieces(xin); });
                 }
                 CSMPN_PHASE();
-                rl_w1_grad<ALG, NOG, 0>(sc, ge, gy, accW1_0, write_input_slice);
+                if constexpr (!kEarly) load_input_pieces(xin);
+                rl_w1_grad<ALG, NOG, 0>(sc, ge, gy, accW1_0, [&](auto d, float* sB) { write_input_slice(xin, d, sB); });
                 ge.stamp(15);
 #pragma unroll
                 for (int t = 0; t < NGL; ++t)

@@ -11,8 +11,10 @@ RLO=$B/k_rl_n3.o
 VF="-mllvm -amdgpu-mfma-vgpr-form"
 # (the vgpr-form rewrite pass of clang 22 crashes on the stamped kernels)
 if [ -n "$STAMPS" ]; then EXTRA="$EXTRA -DCSMPN_STAMPS"; OUT=../csmpn_hip/libcsmpn_hip_stamps.so; RLO=$B/k_rl_n3_stamps.o; VF=""; fi
-hipcc $FLAGS $EXTRA $VF -c k_rl_n3.hip -o $RLO &
-if [ "$1" = "capi" ]; then hipcc $FLAGS -c capi.hip -o $B/capi.o & hipcc $FLAGS -c csr.hip -o $B/csr.o & fi
-wait
+# (a failed compile must not be linked over: wait for every job by pid)
+pids=()
+hipcc $FLAGS $EXTRA $VF -c k_rl_n3.hip -o $RLO & pids+=($!)
+if [ "$1" = "capi" ]; then hipcc $FLAGS -c capi.hip -o $B/capi.o & pids+=($!); hipcc $FLAGS -c csr.hip -o $B/csr.o & pids+=($!); fi
+for p in "${pids[@]}"; do wait $p; done
 hipcc -shared -fPIC --offload-arch=gfx950 $B/capi.o $B/csr.o $B/k_n2.o $B/k_n3.o $B/k_n4.o $B/k_n4m.o $B/k_n5.o $B/k_n5m.o $B/glue.o $B/layers.o $B/k_pl_n5.o $B/k_pl_n5m.o $B/k_plw_n5.o $B/k_plw_n5m.o $RLO -o $OUT
 echo built $OUT
