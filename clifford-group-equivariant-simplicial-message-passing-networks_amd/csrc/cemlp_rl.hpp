@@ -365,83 +365,51 @@ CSMPN_DEV void rl_weight_pipeline(Read&& read, Use&& use) {
 
 // input: I channels all present in the lane (the row's gathered input)
 //   acc[d] += sum_c W[4og + i][c][grade(d)] * X[c][d]
-// (a chunk of them: X = input channels C0 .. C0 + NCH)
+// (a chunk of them: X = input channels C0 .. C0 + NCH). Weight vectors four at a time (rl_weight_pipeline).
 template <class ALG, int WOFF, int C0, int NCH, class GE>
 CSMPN_DEV void rl_linear_x(f4 (&acc)[ALG::D], const float (&X)[NCH][ALG::D], const float* lds, const GE& ge) {
-    constexpr int D = ALG::D;
-    const float* wp = lds + ge.a_x;
-    if constexpr (GE::C == 8) {
-        constexpr int NG = (NCH + 3) / 4;
-        const unsigned a = rl_lds_addr(wp);
-        auto off = [](int g, int i) { const int c = 4 * g + i; return 4 * (WOFF + 4 * (C0 + (c < NCH ? c : NCH - 1))); };
-        rl_weight_pipeline<NG>(
-            [&](auto g, f4 (&w)[4]) { rl_lds_read4<off(g, 0), off(g, 1), off(g, 2), off(g, 3)>(a, w); },
-            [&](auto g, const f4 (&w)[4]) {
-                static_for<0, 4>([&](auto i) {
-                    constexpr int c = 4 * g + i;
-                    if constexpr (c < NCH) static_for<0, D>([&](auto d) { acc[d] = mfma4(w[i][ALG::grade(d)], X[c][d], acc[d]); });
-                });
+    constexpr int D = ALG::D, NG = (NCH + 3) / 4;
+    const unsigned a = rl_lds_addr(lds + ge.a_x);
+    // a short last group reads its last vector again (a valid address; the value is not used)
+    auto off = [](int g, int i) { const int c = 4 * g + i; return 4 * (WOFF + 4 * (C0 + (c < NCH ? c : NCH - 1))); };
+    rl_weight_pipeline<NG>(
+        [&](auto g, f4 (&w)[4]) { rl_lds_read4<off(g, 0), off(g, 1), off(g, 2), off(g, 3)>(a, w); },
+        [&](auto g, const f4 (&w)[4]) {
+            static_for<0, 4>([&](auto i) {
+                constexpr int c = 4 * g + i;
+                if constexpr (c < NCH) static_for<0, D>([&](auto d) { acc[d] = mfma4(w[i][ALG::grade(d)], X[c][d], acc[d]); });
             });
-        return;
-    }
-    static_for<0, NCH>([&](auto c) {
-        const f4 w = ld4(wp + (WOFF + 4 * (C0 + c)));
-        static_for<0, D>([&](auto d) { acc[d] = mfma4(w[ALG::grade(d)], X[c][d], acc[d]); });
-    });
+        });
 }
 
 // input: C channels distributed over the NOG lanes of the row (T = this lane's 4)
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_d(f4 (&acc)[ALG::D], const f4 (&T)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D;
-    if constexpr (NOG == 2) {
-        rl_weight_pipeline<NOG>(
-            [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * WOFF + 16, 4 * WOFF + 32, 4 * WOFF + 48>(rl_lds_addr(lds + ge.a_f[k]), w); },
-            [&](auto k, const f4 (&w)[4]) {
-                static_for<0, 4>([&](auto cl) {
-                    static_for<0, D>([&](auto d) {
-                        acc[d] = mfma4(w[cl][ALG::grade(d)], rl_piece<NOG, k>(T[d][int(cl)]), acc[d]);
-                    });
+    rl_weight_pipeline<NOG>(
+        [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * WOFF + 16, 4 * WOFF + 32, 4 * WOFF + 48>(rl_lds_addr(lds + ge.a_f[k]), w); },
+        [&](auto k, const f4 (&w)[4]) {
+            static_for<0, 4>([&](auto cl) {
+                static_for<0, D>([&](auto d) {
+                    acc[d] = mfma4(w[cl][ALG::grade(d)], rl_piece<NOG, k>(T[d][int(cl)]), acc[d]);
                 });
             });
-        return;
-    }
-    static_for<0, NOG>([&](auto k) {
-        const float* wp = lds + ge.a_f[k];
-        static_for<0, 4>([&](auto cl) {
-            const f4 w = ld4(wp + (WOFF + 4 * cl));
-            static_for<0, D>([&](auto d) {
-                acc[d] = mfma4(w[ALG::grade(d)], rl_piece<NOG, k>(T[d][int(cl)]), acc[d]);
-            });
         });
-    });
 }
 
 // transposed, C -> C:  gx[d] (the lane's 4 INPUT channels) += sum_o W[o][4og + i][grade(d)] * Gin[o][d]
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D, WS = GE::WSC;
-    if constexpr (NOG == 2) {
-        rl_weight_pipeline<NOG>(
-            [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + ge.a_t[k]), w); },
-            [&](auto k, const f4 (&w)[4]) {
-                static_for<0, 4>([&](auto ol) {
-                    static_for<0, D>([&](auto d) {
-                        gx[d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[d]);
-                    });
+    rl_weight_pipeline<NOG>(
+        [&](auto k, f4 (&w)[4]) { rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + ge.a_t[k]), w); },
+        [&](auto k, const f4 (&w)[4]) {
+            static_for<0, 4>([&](auto ol) {
+                static_for<0, D>([&](auto d) {
+                    gx[d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[d]);
                 });
             });
-        return;
-    }
-    static_for<0, NOG>([&](auto k) {
-        const float* wp = lds + ge.a_t[k];
-        static_for<0, 4>([&](auto ol) {
-            const f4 w = ld4(wp + (WOFF + ol * WS));
-            static_for<0, D>([&](auto d) {
-                gx[d] = mfma4(w[ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[d]);
-            });
         });
-    });
 }
 
 // transposed, C -> I0 (the gathered input of block 0): lane (row, og) produces the input channel
@@ -450,33 +418,19 @@ CSMPN_DEV void rl_linear_dt(f4 (&gx)[ALG::D], const f4 (&Gin)[ALG::D], const flo
 template <class ALG, int NOG, int WOFF, class GE>
 CSMPN_DEV void rl_linear_xt(f4 (&gx)[GE::NGL0][ALG::D], const f4 (&Gin)[ALG::D], const float* lds, const GE& ge) {
     constexpr int D = ALG::D, WS = GE::WS1;
-    if constexpr (NOG == 2) {
-        rl_weight_pipeline<GE::NGL0 * NOG>(
-            [&](auto g, f4 (&w)[4]) {
-                constexpr int t = g / NOG, k = g % NOG;
-                rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + (ge.a_ts[k] + ge.c_t[t])), w);
-            },
-            [&](auto g, const f4 (&w)[4]) {
-                constexpr int t = g / NOG, k = g % NOG;
-                static_for<0, 4>([&](auto ol) {
-                    static_for<0, D>([&](auto d) {
-                        gx[t][d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[t][d]);
-                    });
-                });
-            });
-        return;
-    }
-    static_for<0, GE::NGL0>([&](auto t) {
-        static_for<0, NOG>([&](auto k) {
-            const float* wp = lds + (ge.a_ts[k] + ge.c_t[t]);
+    rl_weight_pipeline<GE::NGL0 * NOG>(
+        [&](auto g, f4 (&w)[4]) {
+            constexpr int t = g / NOG, k = g % NOG;
+            rl_lds_read4<4 * WOFF, 4 * (WOFF + WS), 4 * (WOFF + 2 * WS), 4 * (WOFF + 3 * WS)>(rl_lds_addr(lds + (ge.a_ts[k] + ge.c_t[t])), w);
+        },
+        [&](auto g, const f4 (&w)[4]) {
+            constexpr int t = g / NOG, k = g % NOG;
             static_for<0, 4>([&](auto ol) {
-                const f4 w = ld4(wp + (WOFF + ol * WS));
                 static_for<0, D>([&](auto d) {
-                    gx[t][d] = mfma4(w[ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[t][d]);
+                    gx[t][d] = mfma4(w[ol][ALG::grade(d)], rl_piece<NOG, k>(Gin[d][int(ol)]), gx[t][d]);
                 });
             });
         });
-    });
 }
 
 // ---------------------------------------------------------------------------------
