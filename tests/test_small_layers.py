@@ -77,3 +77,52 @@ def test_small_layers_hip(pkg, golden_dir, name, C, layer):
     before = ops.small_layer_launches()
     _run(pkg, golden_dir, name, C, layer, torch.device("cuda:0"), 2e-5, 1e-4)
     assert ops.small_layer_launches() > before, "the standalone HIP entry point did not run"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,C,rows", [("cl30", 28, 1000), ("cl50", 28, 257), ("cl41", 8, 1031), ("cl20", 40, 513)])
+@pytest.mark.parametrize("layer", LAYERS)
+def test_small_layers_hip_vs_host_fp64(pkg, golden_dir, name, C, rows, layer):
+    """Shapes beyond the fixtures (many workgroups, row tails, the hulls width): the HIP entry points against the host
+    formulation of the same module in float64 on the CPU (forward, d/dx, parameter gradients)."""
+    import copy
+    t = np.load(os.path.join(golden_dir, f"tables_{name}.npz"))
+    metric = tuple(t["metric"].tolist())
+    torch.manual_seed(1234)
+    alg = pkg.CliffordAlgebra(metric)
+    mod = _build(pkg, layer, alg, C)
+    with torch.no_grad():
+        for p in mod.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    ref = copy.deepcopy(mod).double()
+    host32 = copy.deepcopy(mod)            # yardstick: the same formulation in float32 on the CPU
+    x = torch.randn(rows, C, 1 << len(metric))
+    gout = torch.randn(rows, C, 1 << len(metric))
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    (yr * gout.double()).sum().backward()
+    xh = x.clone().requires_grad_(True)
+    yh = host32(xh)
+    (yh * gout).sum().backward()
+    dev = torch.device("cuda:0")
+    mod = mod.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    from csmpn_hip import ops
+    before = ops.small_layer_launches()
+    yd = mod(xd)
+    (yd * gout.to(dev)).sum().backward()
+    assert ops.small_layer_launches() > before
+
+    def close(a, h, b, what):
+        # bound: 5e-5 of the tensor's scale, or 4x the float32 host formulation's own error where the layer is
+        # ill-conditioned (norms near the null cone of an indefinite metric)
+        b = b.float()
+        scale = float(b.abs().max().clamp(min=1e-30))
+        err = float((a.cpu() - b).abs().max()) / scale
+        yard = float((h - b).abs().max()) / scale
+        assert err < max(5e-5, 4 * yard), f"{what}: rel err {err:.2e} (float32 host formulation: {yard:.2e})"
+
+    close(yd.detach(), yh.detach(), yr.detach(), "y")
+    close(xd.grad, xh.grad, xr.grad, "gx")
+    for (k, p), (_, h), (_, q) in zip(mod.named_parameters(), host32.named_parameters(), ref.named_parameters()):
+        close(p.grad, h.grad, q.grad, k)
