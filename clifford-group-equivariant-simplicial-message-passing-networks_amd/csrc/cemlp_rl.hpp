@@ -31,6 +31,11 @@
 //  * every LDS address is (one of a few per-lane bases, RlGeo) + a compile-time immediate: the
 //    kernels are fully unrolled and a loop-invariant address per access would otherwise be hoisted
 //    out of the tile loop and spilled (round-2 first version: 200 spilled address registers).
+//  * one wave per SIMD in the backward means every wait that directly follows its load is dead time; where the
+//    scheduler (under ~500 live registers) produced such waits, the order is stated in the source: parameter
+//    pointers as scalar values + batched value loads (rl_stage_store), four weight vectors in flight under the
+//    previous group's MFMAs (rl_weight_pipeline), all input rows of a tile requested up front (PIN), the re-gather
+//    for the weight gradient issued under the MVSiLU backward (early_loads). DESIGN.md 4.1.
 //  * gathers are per-lane 16-byte loads of the lane's own rows (the NOG lanes of a row issue the same
 //    addresses in the same instruction); scatters go through a per-wave LDS tile so that one atomic
 //    instruction covers whole rows (segment-merged by target for the target-sorted edge list).
