@@ -1145,7 +1145,10 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 static_for<0, (decltype(n_total)::value + 7) / 8>([&](auto q8) {
                     constexpr int off = 8 * q8, NCH = decltype(n_total)::value - off < 8 ? decltype(n_total)::value - off : 8;
                     float X[NCH][D];
-                    rl_load_channels<ALG, NCH>(X, 0, pa + off * D);
+                    // edge kernels: the loads of the last (attribute) chunk are pinned to this point (16 channels, stage timers:
+                    // edge backward -4 % in one A/B, within noise in the bench line; the node kernels measured +2 % with it)
+                    if constexpr (NCH < 8 && MODE == MODE_EDGE) rl_load_channels<ALG, NCH, NCH, true>(X, 0, pa + off * D);
+                    else rl_load_channels<ALG, NCH>(X, 0, pa + off * D);
                     if (pb) {
                         float Y[NCH][D];
                         rl_load_channels<ALG, NCH>(Y, 0, pb + off * D);
