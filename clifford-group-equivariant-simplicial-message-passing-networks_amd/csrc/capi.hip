@@ -15,6 +15,7 @@
 #include "cemlp_kernel.hpp"
 #include "launch.hpp"
 #include "rl_launch.hpp"
+#include "cl_launch.hpp"
 #include "pl_launch.hpp"
 #include "plw_launch.hpp"
 
@@ -499,7 +500,22 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     const int ch = blocks[0].out_features;
     for (int k = 0; k < nblk; ++k)
         if (blocks[k].out_features != ch || (k > 0 && blocks[k].in_features != ch)) return 0;
-    return cemlp_rl_partial_floats_n3(nblk, ch, blocks[0].in_features) * sizeof(float) * kRlPartialGroups;
+    const size_t rl = cemlp_rl_partial_floats_n3(nblk, ch, blocks[0].in_features) * sizeof(float) * kRlPartialGroups;
+    // (row, channel)-per-lane backward (cemlp_cl.hpp): one slice per workgroup of a block launch; the same region
+    const int i0 = blocks[0].in_features;
+    size_t clf = cemlp_cl_partial_floats_n3(MODE_EDGE, nblk, ch, i0);
+    const size_t cln = cemlp_cl_partial_floats_n3(MODE_NODE, nblk, ch, i0);
+    clf = cln > clf ? cln : clf;
+    const size_t cl = clf * sizeof(float) * kClMaxBwdGroups;
+    return cl > rl ? cl : rl;
+}
+// the (row, channel)-per-lane backward hands d/d(block-1 input) from its block-1 launch to its block-0 launch through
+// one more [rows, C, D] region behind the saved block inputs (as the wide parity-lane kernels do)
+bool cl_shape(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n != 3 || nblk != 2) return false;
+    const int ch = blocks[0].out_features, i0 = blocks[0].in_features;
+    if (blocks[1].out_features != ch || blocks[1].in_features != ch) return false;
+    return has_cemlp_cl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_cl_n3(MODE_NODE, nblk, ch, i0);
 }
 
 // bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
@@ -546,6 +562,32 @@ bool rl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     if (!has_cemlp_rl_n3(mode, C.nblk, ch, C.b[0].I)) return false;
     if (bwd) {
         const size_t pb = cemlp_rl_partial_floats_n3(C.nblk, ch, C.b[0].I) * sizeof(float) * kRlPartialGroups;
+        if (!plan.workspace || plan.workspace_bytes < pb) return false;
+    }
+    return true;
+}
+
+// (row, channel)-per-lane kernels (cemlp_cl.hpp): Cl(3,0), two blocks of 8 channels, the EGCL attribute widths of S1.
+// CSMPN_NO_CL=1 leaves these shapes to the row-per-lane kernels (A/B measurements, parity tests of both paths).
+bool cl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
+    static const bool off = getenv("CSMPN_NO_CL") && atoi(getenv("CSMPN_NO_CL"));
+    if (off || id != ALG_N3) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    const int ch = C.b[0].O;
+    for (int k = 0; k < C.nblk; ++k) {
+        if (C.b[k].O != ch || !C.b[k].w1_sub) return false;
+        if (k > 0 && C.b[k].I != ch) return false;
+    }
+    if (mode == MODE_EDGE && (io.seg[0].ch != ch || C.b[0].I != ch + (io.nseg > 1 ? io.seg[1].ch : 0))) return false;
+    if (mode == MODE_NODE && (io.seg[0].ch != ch || io.seg[1].ch != ch || C.b[0].I != 2 * ch + (io.nseg > 2 ? io.seg[2].ch : 0))) return false;
+    if (mode != MODE_EDGE && mode != MODE_NODE) return false;
+    if (bwd && !io.saved) return false;
+    *channels = ch;
+    *i0 = C.b[0].I;
+    if (!has_cemlp_cl_n3(mode, C.nblk, ch, C.b[0].I)) return false;
+    if (bwd) {
+        const size_t pb = cemlp_cl_partial_floats_n3(mode, C.nblk, ch, C.b[0].I) * sizeof(float) * kClMaxBwdGroups;
         if (!plan.workspace || plan.workspace_bytes < pb) return false;
     }
     return true;
@@ -647,6 +689,28 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     }
     {
         int channels = 0, i0 = 0;
+        if (cl_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
+            const long rows_per_wave = 64 / channels;
+            const long tiles = (io.rows + rows_per_wave - 1) / rows_per_wave;
+            // tile t belongs to wave t % (4 grid): four 4-wave workgroups per CU in the forward (~100 VGPRs), two in a
+            // block backward (<= 256)
+            const long cap = bwd ? kClMaxBwdGroups : kClMaxFwdGroups;
+            const long groups = (tiles + 3) / 4;
+            const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            if (bwd) {
+                const size_t pb = cemlp_cl_partial_floats_n3(mode, plan.C.nblk, channels, i0) * sizeof(float) * kClMaxBwdGroups;
+                io.rl_partials = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb) & ~(size_t)15));
+                io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // see csmpn_cemlp_saved_floats_per_row
+            }
+            bool handled = false;
+            static const bool debug_cl = getenv("CSMPN_DEBUG") != nullptr;
+            if (debug_cl) fprintf(stderr, "[csmpn] cl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
+            HIP_TRY(launch_cemlp_cl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
+            if (handled) return CSMPN_OK;
+        }
+    }
+    {
+        int channels = 0, i0 = 0;
         if (rl_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
             const long rows_per_wave = 64 / (channels / 4);
             const long tiles = (io.rows + rows_per_wave - 1) / rows_per_wave;
@@ -669,7 +733,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     }
     if (io.row_store)
         return fail(CSMPN_ERR_UNSUPPORTED,
-                    "CSMPN_FLAG_DETERMINISTIC needs the row-per-lane kernels (Cl(3,0), 8 or 16 channels) or the wide parity-lane "
+                    "CSMPN_FLAG_DETERMINISTIC needs the lane kernels of Cl(3,0) (8 or 16 channels) or the wide parity-lane "
                     "kernels (Cl(5,0) / Cl(4,1), 16 / 24 / 28 / 32 channels), two blocks with saved block inputs: the other "
                     "kernel families sum parameter gradients with float atomics");
     // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
@@ -882,6 +946,7 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
     if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
+    if (cl_shape(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane backward likewise
     return ch << n;
 }
 

@@ -1,0 +1,58 @@
+"""Per-phase shader-clock breakdown of the four EGCL stages on the (row, channel)-per-lane kernels (diagnostic stamps
+build only: tools/_bin/libcsmpn_hip_stamps.so, see tools/cl_stamps_build.sh). Shares, not durations: the stamp fences
+forbid overlaps across phases. Backward stages: both block launches add into the same slots."""
+import ctypes, importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = "clifford-group-equivariant-simplicial-message-passing-networks_amd"
+os.environ["CSMPN_LIB"] = os.path.join(ROOT, "tools", "_bin", "libcsmpn_hip_stamps.so")
+sys.path.insert(0, ROOT)
+import torch
+pkg = importlib.import_module(PKG)
+from csmpn_hip import native, ops
+import bench
+
+FWD = ["setup(stage tables)", "loads(wait)", "W1 mix b0", "silu b0", "linR/L b0", "norm b0", "gp b0", "layernorm b0",
+       "W1 mix b1", "silu b1", "linR/L b1", "norm b1", "gp b1", "layernorm b1", "store/scatter"]
+BWD = ["setup(stage tables)", "loads(wait)", "r:W1 mix", "r:silu", "r:linR/L", "r:norm", "r:gp", "r:layernorm",
+       "b:layernorm", "b:linL^T", "b:gp", "b:norm", "b:linR^T", "b:wgradRL(mfma)", "b:silu", "b:wgradW1(mfma)",
+       "b:W1^T+store/scatter", "end-of-kernel sums"]
+
+def main(workload="S1"):
+    dev = torch.device("cuda:0")
+    metric, C, N, E = bench.WORKLOADS[workload]
+    (h, ei, ea, na), _ = bench.make_inputs(metric, C, N, E, 0, E, dev)
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
+    lib = native.lib()
+    lib.csmpn_debug_set_stamps.argtypes = [ctypes.c_void_p]
+    lib.csmpn_debug_set_stamps.restype = None
+    st = torch.zeros(25, dtype=torch.int64, device=dev)
+    be, spec = ops.HipBackend, layer.spec()
+    csr = ops.get_csr(ei, N)
+    pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+    gout = torch.ones(N, C, 1 << len(metric), device=dev)
+    agg, se = be.edge_forward(spec, csr, h, ea, pe)
+    out, sn = be.node_forward(spec, csr.deg, h, agg, na, pn)
+    gh, g_agg, _, _ = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, sn)
+    stages = {
+        "edge_fwd": lambda: be.edge_forward(spec, csr, h, ea, pe),
+        "node_fwd": lambda: be.node_forward(spec, csr.deg, h, agg, na, pn),
+        "node_bwd": lambda: be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, sn),
+        "edge_bwd": lambda: be.edge_backward(spec, csr, h, ea, pe, g_agg, gh, False, se),
+    }
+    for name, fn in stages.items():
+        fn(); torch.cuda.synchronize()
+        st.zero_(); torch.cuda.synchronize()
+        lib.csmpn_debug_set_stamps(st.data_ptr())
+        fn(); torch.cuda.synchronize()
+        lib.csmpn_debug_set_stamps(None)
+        v = st.cpu().tolist()
+        waves, tot = v[24], sum(v[:24])
+        print(f"== {name}: {waves} waves, {tot / max(waves,1) / 1e3:.1f} kcycles per wave")
+        names = FWD if name.endswith("fwd") else BWD
+        for i, nm in enumerate(names):
+            if v[i]:
+                print(f"   {nm:24s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "S1")
