@@ -694,7 +694,12 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             const long tiles = (io.rows + rows_per_wave - 1) / rows_per_wave;
             // tile t belongs to wave t % (4 grid): four 4-wave workgroups per CU in the forward (~100 VGPRs), two in a
             // block backward (<= 256)
-            const long cap = bwd ? kClMaxBwdGroups : kClMaxFwdGroups;
+            long cap = bwd ? kClMaxBwdGroups : kClMaxFwdGroups;
+            // experiments: fewer resident workgroups (never more: the partial buffer has kClMaxBwdGroups slices)
+            static const long cap_f = getenv("CSMPN_CL_CAP_FWD") ? atol(getenv("CSMPN_CL_CAP_FWD")) : 0;
+            static const long cap_b = getenv("CSMPN_CL_CAP_BWD") ? atol(getenv("CSMPN_CL_CAP_BWD")) : 0;
+            if (!bwd && cap_f > 0 && cap_f < 4096) cap = cap_f;
+            if (bwd && cap_b > 0 && cap_b < cap) cap = cap_b;
             const long groups = (tiles + 3) / 4;
             const unsigned grid = (unsigned)(groups < cap ? groups : cap);
             if (bwd) {

@@ -36,6 +36,7 @@
 namespace csmpn {
 
 constexpr int kClWaves = 4;          // waves per workgroup
+constexpr int kClSliceCap = 512;     // workgroups of a backward launch = slices of partial sums per block
 constexpr int kClParStride = 36;     // floats per channel in the per-channel parameter table
 
 CSMPN_DEV f4 cl_ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
@@ -141,6 +142,10 @@ CSMPN_DEV void cl_pin(f4 (&w)[NK]) {
 template <int C, int NROT, int TOFF, int BATCH = 4>
 CSMPN_DEV void cl_mix(float (&acc)[8], const float (&x)[8], const float* ldsw) {
     static_assert(NROT % BATCH == 0, "whole batches");
+#ifdef CL_X_NOMIX   // timing experiment only (results wrong): rotation 0 alone
+    cl_fmac8<0>(acc, x, cl_ld4(ldsw + TOFF));
+    return;
+#endif
     constexpr int NB = NROT / BATCH;
     f4 w[BATCH];
 #pragma unroll
@@ -554,11 +559,15 @@ CSMPN_DEV void cl_block_backward(const float* ldsw, const float* ldsp, const ClF
     cl_mix<C, C, TB::WRT>(gz, gR, ldsw);
     stamp(sid + 4);
     // ---- weight gradients of linear_right and linear_left on the MFMA, B = z = gate * y
+#ifndef CL_X_NOMFMA
     static_for<0, D>([&](auto d) {
         constexpr int g = ALG::grade(d);
         accR[g] = mfma16(gR[d], zf[d], accR[g]);
         accL[g] = mfma16(ggp[d], zf[d], accL[g]);
     });
+#else
+    static_for<0, D>([&](auto d) { constexpr int g = ALG::grade(d); accR[g][0] += gR[d] * zf[d]; accL[g][0] += ggp[d] * zf[d]; });
+#endif
     stamp(sid + 5);
     // ---- MVSiLU backward -> gy
     const f4 sa = cl_ld4(ldsp + (TB::par + 4));
@@ -603,6 +612,11 @@ CSMPN_DEV void cl_st8(float* p, const float (&x)[8]) {
     cl_st4(p, f4{x[0], x[1], x[2], x[3]});
     cl_st4(p + 4, f4{x[4], x[5], x[6], x[7]});
 }
+#ifdef CL_X_NOOUT   // timing experiment only (results wrong): row stores go to the wave's LDS scratch
+#define CL_GST8(gp, lp, x) cl_st8(lp, x)
+#else
+#define CL_GST8(gp, lp, x) cl_st8(gp, x)
+#endif
 
 // Rows of a staged tile [RPW][ROWLEN + 4] -> atomic adds into table rows of ROWLEN floats; lane = column. The row
 // targets travel through SGPRs (v_readlane of the channel-0 lane of the row). Adds the rows to table[t_add[row]] (rows
@@ -617,7 +631,11 @@ CSMPN_DEV void cl_scatter(const float* sc, int t_add, int t_sub, float* table, i
         const int colx = 64 * cc + lane;
         const float* col = sc + colx;
         auto flush = [&](int target, float a) {
+#ifndef CL_X_NOOUT   // timing experiment only (results wrong): no atomics
             if (target >= 0) atomicAdd(table + (size_t)target * ROWLEN + colx, a);
+#else
+            if (target == -12345) atomicAdd(table + (size_t)target * ROWLEN + colx, a);
+#endif
         };
         float val[RPW];
 #pragma unroll
@@ -748,13 +766,6 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
     const int c = MP::chan(lane), r = MP::row(lane);
     float* sc = lds + tab_floats + wave * (RPW * SS);   // scatter staging tile (edge program)
     ClStamp stamp(0);
-    {
-        const int dir = cl_probe_dir<C>(c);
-        cl_stage_block<ALG, C, T0, false>(Cd.b[0], lds, threadIdx.x, dir);
-        if constexpr (NBLK > 1) cl_stage_block<ALG, C, T1, false>(Cd.b[1], lds + T0::total, threadIdx.x, dir);
-    }
-    __syncthreads();
-    stamp(0);
     const float* ldsw0 = lds + 4 * c;
     const float* ldsp0 = lds + kClParStride * c;
     const float* ldsw1 = ldsw0 + T0::total;
@@ -771,6 +782,14 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
     ClRaw<ALG, C, MODE, NA> raw;
     raw.template issue<T0>(io, T, c);
     Tn.template load<NA>(io, tile0 + tstride, r);
+    // the first tile's rows travel while the tables are staged
+    {
+        const int dir = cl_probe_dir<C>(c);
+        cl_stage_block<ALG, C, T0, false>(Cd.b[0], lds, threadIdx.x, dir);
+        if constexpr (NBLK > 1) cl_stage_block<ALG, C, T1, false>(Cd.b[1], lds + T0::total, threadIdx.x, dir);
+    }
+    __syncthreads();
+    stamp(0);
     for (long tile = tile0; tile < ntiles; tile += tstride) {
         raw.pin();
         stamp(1);
@@ -801,11 +820,11 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
         raw.template issue<T0>(io, T, c);
         Tn.template load<NA>(io, tile + 2 * tstride, r);
         if constexpr (NBLK > 1) {
-            if (io.save && Tc.valid) cl_st8(io.save + (size_t)Tc.row * ROW + c * D, in1);
+            if (io.save && Tc.valid) CL_GST8(io.save + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, in1);
         }
         if constexpr (MODE == MODE_EDGE) {
             if (io.row_store) {
-                if (Tc.valid) cl_st8(io.agg + (size_t)Tc.lrow * ROW + c * D, out);
+                if (Tc.valid) CL_GST8(io.agg + (size_t)Tc.lrow * ROW + c * D, sc + r * SS + c * D, out);
             } else {
                 cl_st8(sc + r * SS + c * D, out);
                 cl_scatter<C, ROW, false>(sc, Tc.valid ? Tc.i_dst : -1, -1, io.agg, lane);
@@ -817,7 +836,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 #pragma unroll
                 for (int d = 0; d < D; ++d) out[d] += res[d];
             }
-            cl_st8(io.y + (size_t)Tc.row * ROW + c * D, out);
+            CL_GST8(io.y + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, out);
         }
         stamp(14);
     }
@@ -855,9 +874,6 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
     const int c = MP::chan(lane), r = MP::row(lane);
     float* sc = lds + TB::total + wave * scratch;
     ClStamp stamp(0);
-    cl_stage_block<ALG, C, TB, true>(Cd.b[K], lds, threadIdx.x, cl_probe_dir<C>(c));
-    __syncthreads();
-    stamp(0);
     const float* ldsw = lds + 4 * c;
     const float* ldsp = lds + kClParStride * c;
 
@@ -893,6 +909,10 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
     T.template load<NA>(io, tile0, r);
     issue(T);
     Tn.template load<NA>(io, tile0 + tstride, r);
+    // the first tile's rows travel while the tables are staged
+    cl_stage_block<ALG, C, TB, true>(Cd.b[K], lds, threadIdx.x, cl_probe_dir<C>(c));
+    __syncthreads();
+    stamp(0);
     for (long tile = tile0; tile < ntiles; tile += tstride) {
         if constexpr (K == 0) {
             asm volatile("" : "+v"(g0), "+v"(g1));
@@ -925,9 +945,13 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
             cl_block_backward<ALG, C, TB>(ldsw, ldsp, S, gout, gy, sm, accR, accL, stamp, 8);
         }
         // MVLinear weight gradient: A = gy, B = the pass's input blade
+#ifndef CL_X_NOMFMA
         static_for<0, NP>([&](auto p) {
             static_for<0, D>([&](auto d) { accW1[p][ALG::grade(d)] = mfma16(gy[d], x[p][d], accW1[p][ALG::grade(d)]); });
         });
+#else
+        static_for<0, NP>([&](auto p) { static_for<0, D>([&](auto d) { accW1[p][ALG::grade(d)][0] += gy[d] * x[p][d]; }); });
+#endif
         stamp(15);
         // next tile's rows, then this tile's stores / atomics
         T = Tn;
@@ -939,7 +963,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
 #pragma unroll
             for (int d = 0; d < D; ++d) gx[d] = 0.f;
             cl_mix<C, C, TB::W1T(0)>(gx, gy, ldsw);
-            if (Tc.valid) cl_st8(io.plw_g1 + (size_t)Tc.row * ROW + c * D, gx);
+            if (Tc.valid) CL_GST8(io.plw_g1 + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, gx);
         } else if constexpr (MODE == MODE_EDGE) {
             if (io.gx[0]) {
                 float gx[D];
@@ -947,7 +971,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
                 for (int d = 0; d < D; ++d) gx[d] = 0.f;
                 cl_mix<C, C, TB::W1T(0)>(gx, gy, ldsw);
                 if (io.row_store) {
-                    if (Tc.valid) cl_st8(io.gx[0] + (size_t)Tc.lrow * ROW + c * D, gx);
+                    if (Tc.valid) CL_GST8(io.gx[0] + (size_t)Tc.lrow * ROW + c * D, sc + r * SS + c * D, gx);
                 } else {
                     cl_st8(sc + r * SS + c * D, gx);
                     cl_scatter<C, ROW, true>(sc, Tc.valid ? Tc.i_dst : -1, Tc.valid ? Tc.i_src : -1, io.gx[0], lane);
@@ -959,7 +983,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
 #pragma unroll
                     for (int d = 0; d < D; ++d) gx[d] = 0.f;
                     cl_mix<C, C, TB::W1T(1)>(gx, gy, ldsw);
-                    if (Tc.valid && c < NA) cl_st8(io.gx[1] + (size_t)Tc.i_perm * (NA * D) + c * D, gx);
+                    if (Tc.valid && c < NA) CL_GST8(io.gx[1] + (size_t)Tc.i_perm * (NA * D) + c * D, sc + r * SS + c * D, gx);
                 }
             }
         } else {
@@ -975,7 +999,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
 #pragma unroll
                         for (int d = 0; d < D; ++d) gx[d] += res[d];
                     }
-                    cl_st8(io.gx[0] + (size_t)Tc.row * ROW + c * D, gx);
+                    CL_GST8(io.gx[0] + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, gx);
                 }
             }
             if (io.gx[1]) {
@@ -985,7 +1009,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
                 cl_mix<C, C, TB::W1T(1)>(gx, gy, ldsw);
 #pragma unroll
                 for (int d = 0; d < D; ++d) gx[d] *= Tc.scale;
-                if (Tc.valid) cl_st8(io.gx[1] + (size_t)Tc.row * ROW + c * D, gx);
+                if (Tc.valid) CL_GST8(io.gx[1] + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, gx);
             }
             if constexpr (NA > 0) {
                 if (io.gx[2]) {
@@ -993,13 +1017,24 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
 #pragma unroll
                     for (int d = 0; d < D; ++d) gx[d] = 0.f;
                     cl_mix<C, C, TB::W1T(2)>(gx, gy, ldsw);
-                    if (Tc.valid && c < NA) cl_st8(io.gx[2] + (size_t)Tc.row * (NA * D) + c * D, gx);
+                    if (Tc.valid && c < NA) CL_GST8(io.gx[2] + (size_t)Tc.row * (NA * D) + c * D, sc + r * SS + c * D, gx);
                 }
             }
         }
         stamp(16);
     }
 
+#ifdef CL_X_NOEND   // timing experiment only (results wrong): the sums are kept alive, nothing else
+    {
+        f4 t = accR[0] + accL[0];
+#pragma unroll
+        for (int g = 0; g < G; ++g) { t += accR[g] + accL[g];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) t += accW1[p][g]; }
+        cl_st4(sc + 4 * lane, t);
+    }
+    if (false)
+#endif
     // ---- end of the launch: this wave's sums -> image of the slice in its scratch; the workgroup adds its four
     // images in wave order and writes its slice (coalesced 16-byte stores)
     {
@@ -1043,7 +1078,9 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
             if (q == 0 && (C == 16 || (lane & 1) == 0)) img[PT::pS + PT::off(idx) + c * PT::stride(idx)] = s;
         });
         __syncthreads();
-        float* part = io.rl_partials + (size_t)blockIdx.x * PT::total;
+        // block k's slices start behind those of the blocks 0 .. k - 1 (kClSliceCap slices each)
+        float* part = io.rl_partials + (K == 0 ? 0 : (size_t)kClSliceCap * ClPart<ALG, C, ClTab<C, MODE, NA, 0, true>::I>::total) +
+                      (size_t)blockIdx.x * PT::total;
         const float* img0 = lds + TB::total;
         static_assert(PT::total % 4 == 0, "slice length");
         for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kClWaves) {
@@ -1064,32 +1101,34 @@ constexpr size_t cl_bwd_lds_bytes() {
     return sizeof(float) * (TB::total + kClWaves * (tile > PT::total ? tile : PT::total) + ClSums<ClRed<ALG>::n>::floats_per_wg);
 }
 
-// second kernel of a block backward: grads += sum over the workgroups' slices, fixed order (deterministic).
-// A workgroup takes 16 consecutive elements; thread (j = tid & 15, w0 = tid >> 4) adds the slices w0, w0 + 16, ...
-// of element 16 b + j, the 16 partial sums meet in LDS and are added in order.
-template <class ALG, int C, int I>
-__global__ void __launch_bounds__(256) cl_reduce_kernel(const DevBlock B, const float* part, int nslices) {
-    using PT = ClPart<ALG, C, I>;
+// last kernel of a backward: grads += sum over the workgroups' slices of EVERY block launch, fixed order
+// (deterministic). The slices of block k start at part + k * kSliceCap * (slice length of block 0 ... k - 1). One wave per
+// element: lane g adds the slices g, g + 64, ... (all loads in flight together), then a butterfly over the 64 lanes.
+template <class ALG, int C, int I0, int NBLK>
+__global__ void __launch_bounds__(256) cl_reduce_kernel(const DevCemlp Cd, const float* part, int nslices, int slice_cap) {
     constexpr int G = ALG::G;
-    __shared__ float red[16][17];
-    const int j = threadIdx.x & 15, w0 = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + j;
-    float s = 0.f;
-    if (e < PT::total) {
-        const float* p = part + e;
-        int w = w0;
-        for (; w + 48 < nslices; w += 64) {   // four independent loads in flight
-            const float a = p[(size_t)w * PT::total], b = p[(size_t)(w + 16) * PT::total];
-            const float cc = p[(size_t)(w + 32) * PT::total], d = p[(size_t)(w + 48) * PT::total];
-            s += (a + b) + (cc + d);
-        }
-        for (; w < nslices; w += 16) s += p[(size_t)w * PT::total];
-    }
-    red[w0][j] = s;
-    __syncthreads();
-    if (w0 != 0 || e >= PT::total) return;
+    using P0 = ClPart<ALG, C, I0>;
+    using P1 = ClPart<ALG, C, C>;
+    constexpr int total = P0::total + (NBLK > 1 ? P1::total : 0);
+    const int g = threadIdx.x & 63;
+    int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= total) return;   // whole waves leave together
+    const int k = (NBLK > 1 && e >= P0::total) ? 1 : 0;
+    const int len = k == 0 ? P0::total : P1::total;
+    const float* p = part + (k == 0 ? 0 : (size_t)slice_cap * P0::total);
+    if (k == 1) e -= P0::total;
+    float v[8];
 #pragma unroll
-    for (int w = 1; w < 16; ++w) s += red[w][j];
+    for (int i = 0; i < 8; ++i) {
+        const int sl = g + 64 * i;
+        v[i] = sl < nslices ? p[(size_t)sl * len + e] : 0.f;
+    }
+    float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if (g != 0) return;
+    const DevBlock& B = Cd.b[k];
+    const int I = k == 0 ? I0 : C;
     int f = e;
     float* dst = nullptr;
     const int nW1 = C * I * G, nWC = C * C * G;
@@ -1098,13 +1137,13 @@ __global__ void __launch_bounds__(256) cl_reduce_kernel(const DevBlock B, const 
     else if ((f -= nWC) < nWC) dst = B.gWL + f;
     else {
         f -= nWC;
-        if (f < PT::qsa) dst = B.has_b1 ? B.gb1 + f : nullptr;
-        else if (f < PT::qsb) dst = B.gsa + (f - PT::qsa);
-        else if (f < PT::qw) dst = B.gsb + (f - PT::qsb);
-        else if (f < PT::qan) dst = B.gw + (f - PT::qw);
-        else if (f < PT::qbL) dst = B.gan + (f - PT::qan);
-        else if (f < PT::qla) dst = B.gbL + (f - PT::qbL);
-        else dst = B.gla + (f - PT::qla);
+        if (f < P0::qsa) dst = B.has_b1 ? B.gb1 + f : nullptr;
+        else if (f < P0::qsb) dst = B.gsa + (f - P0::qsa);
+        else if (f < P0::qw) dst = B.gsb + (f - P0::qsb);
+        else if (f < P0::qan) dst = B.gw + (f - P0::qw);
+        else if (f < P0::qbL) dst = B.gan + (f - P0::qan);
+        else if (f < P0::qla) dst = B.gbL + (f - P0::qbL);
+        else dst = B.gla + (f - P0::qla);
     }
     if (dst) *dst += s;
 }

@@ -6,7 +6,7 @@
 
 namespace csmpn {
 constexpr int kClMaxFwdGroups = 1024;   // 4-wave workgroups of a forward launch: four per CU (4 waves per SIMD)
-constexpr int kClMaxBwdGroups = 512;    // ... of a backward launch: two per CU; one slice of the partial buffer each
+constexpr int kClMaxBwdGroups = 512;    // ... of a backward launch: two per CU; one slice of partial sums each (= kClSliceCap of cemlp_cl.hpp)
 #define CSMPN_DECLARE_CL(tag)                                                                                  \
     bool has_cemlp_cl_##tag(int mode, int nblk, int channels, int i0);                                          \
     size_t cemlp_cl_partial_floats_##tag(int mode, int nblk, int channels, int i0);                             \
