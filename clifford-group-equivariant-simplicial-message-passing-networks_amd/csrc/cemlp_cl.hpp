@@ -853,13 +853,7 @@ constexpr size_t cl_fwd_lds_bytes() {
 // gathers it by target) or from the hand-over rows io.plw_g1; d/d(input of block K) goes to the hand-over rows (K > 0)
 // or to the program's gradient targets (K = 0). Block K > 0 reads its input from the saved rows.
 template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-__global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
-    typedef const char __attribute__((address_space(4))) * KArgPtr;
-    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
-    const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
-    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
-    (void)C_arg; (void)io_arg;
+CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, ClStamp& stamp) {
     using MP = ClMap<C>;
     using TB = ClTab<C, MODE, NA, K, true>;
     using PT = ClPart<ALG, C, TB::I>;
@@ -868,12 +862,10 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
     static_assert(K >= 0 && K < NBLK && NBLK <= 2, "block index");
     constexpr bool kLast = K == NBLK - 1;
     constexpr int scratch = (RPW * SS > PT::total ? RPW * SS : PT::total);   // staging tile / image of the slice
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds = smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = MP::chan(lane), r = MP::row(lane);
     float* sc = lds + TB::total + wave * scratch;
-    ClStamp stamp(0);
     const float* ldsw = lds + 4 * c;
     const float* ldsp = lds + kClParStride * c;
 
@@ -1091,14 +1083,45 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
         }
     }
     stamp(17);
-    stamp.flush(io.stamps, lane);
 }
 template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-constexpr size_t cl_bwd_lds_bytes() {
+constexpr size_t cl_bwd_block_lds_bytes() {
     using TB = ClTab<C, MODE, NA, K, true>;
     using PT = ClPart<ALG, C, TB::I>;
     constexpr int tile = ClMap<C>::RPW * (C * ALG::D + 4);
     return sizeof(float) * (TB::total + kClWaves * (tile > PT::total ? tile : PT::total) + ClSums<ClRed<ALG>::n>::floats_per_wg);
+}
+template <class ALG, int C, int MODE, int NBLK, int NA>
+constexpr size_t cl_bwd_lds_bytes() {
+    size_t m = cl_bwd_block_lds_bytes<ALG, C, MODE, NBLK, NA, 0>();
+    if constexpr (NBLK > 1) {
+        constexpr size_t m1 = cl_bwd_block_lds_bytes<ALG, C, MODE, NBLK, NA, 1>();
+        if (m1 > m) m = m1;
+    }
+    return m;
+}
+// The backward kernel: the blocks one after the other (last block first) in ONE launch. A wave keeps its tiles from
+// block to block, so the hand-over rows d/d(block input) it reads in block k - 1 are the ones it wrote itself in block k
+// (through L2: the region is not read earlier in the launch, its lines cannot sit stale in this CU's L1; the stores are
+// drained before the workgroup's barrier) - no grid-wide synchronisation, one prologue less, and the node program
+// (one tile per wave) is a single launch.
+template <class ALG, int C, int MODE, int NBLK, int NA>
+__global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+    typedef const char __attribute__((address_space(4))) * KArgPtr;
+    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
+    const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
+    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
+    (void)C_arg; (void)io_arg;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ClStamp stamp(0);
+    if constexpr (NBLK > 1) {
+        cl_bwd_block<ALG, C, MODE, NBLK, NA, 1>(Cd, io, smem, stamp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
+        __syncthreads();                                   // ... and every wave is done with the LDS tables and images
+    }
+    cl_bwd_block<ALG, C, MODE, NBLK, NA, 0>(Cd, io, smem, stamp);
+    stamp.flush(io.stamps, threadIdx.x & 63);
 }
 
 // last kernel of a backward: grads += sum over the workgroups' slices of EVERY block launch, fixed order
