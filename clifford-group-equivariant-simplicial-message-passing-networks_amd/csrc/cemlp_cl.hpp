@@ -852,8 +852,10 @@ constexpr size_t cl_fwd_lds_bytes() {
 // backward of block K (launched last block first). d/d(out of block K) comes from io.gy (last block; the edge program
 // gathers it by target) or from the hand-over rows io.plw_g1; d/d(input of block K) goes to the hand-over rows (K > 0)
 // or to the program's gradient targets (K = 0). Block K > 0 reads its input from the saved rows.
+struct ClCarry { f4 a, b; };
 template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, ClStamp& stamp) {
+CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const ClCarry carry_in, bool single, ClStamp& stamp) {
+    f4 carry_a = carry_in.a, carry_b = carry_in.b;
     using MP = ClMap<C>;
     using TB = ClTab<C, MODE, NA, K, true>;
     using PT = ClPart<ALG, C, TB::I>;
@@ -861,17 +863,19 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
     constexpr int D = ALG::D, G = ALG::G, ROW = C * D, RPW = MP::RPW, SS = ROW + 4, NP = TB::NP;
     static_assert(K >= 0 && K < NBLK && NBLK <= 2, "block index");
     constexpr bool kLast = K == NBLK - 1;
-    constexpr int scratch = (RPW * SS > PT::total ? RPW * SS : PT::total);   // staging tile / image of the slice
-    float* lds = smem;
+    // per-wave scratch: staging tile / image of the slice (the larger of the blocks' images: one layout for the launch)
+    constexpr int img_max = NBLK > 1 && ClPart<ALG, C, C>::total > ClPart<ALG, C, ClTab<C, MODE, NA, 0, true>::I>::total
+                                ? ClPart<ALG, C, C>::total : ClPart<ALG, C, ClTab<C, MODE, NA, 0, true>::I>::total;
+    constexpr int scratch = (RPW * SS > img_max ? RPW * SS : img_max);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = MP::chan(lane), r = MP::row(lane);
-    float* sc = lds + TB::total + wave * scratch;
-    const float* ldsw = lds + 4 * c;
-    const float* ldsp = lds + kClParStride * c;
+    float* sc = work + wave * scratch;
+    const float* ldsw = tab + 4 * c;
+    const float* ldsp = tab + kClParStride * c;
 
     // persistent sums of this wave
     f4 accW1[NP][G], accR[G], accL[G];
-    ClSums<RM::n> sm(lds + TB::total + kClWaves * scratch + 4 * threadIdx.x);
+    ClSums<RM::n> sm(work + kClWaves * scratch + 4 * threadIdx.x);
     sm.zero();
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -888,7 +892,11 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
     auto issue = [&](const ClTile<C, MODE>& Tl) {
         const float* gsrc = (kLast ? io.gy + (size_t)(MODE == MODE_EDGE ? (long)Tl.i_dst : Tl.lrow) * ROW
                                    : io.plw_g1 + (size_t)Tl.lrow * ROW) + c * D;
-        g0 = cl_ld4(gsrc); g1 = cl_ld4(gsrc + 4);
+        if (kLast || !single) {
+            g0 = cl_ld4(gsrc); g1 = cl_ld4(gsrc + 4);
+        } else {   // one tile per wave: d/d(out) of this block stayed in registers
+            g0 = carry_a; g1 = carry_b;
+        }
         if constexpr (K == 0) {
             raw.template issue<TB>(io, Tl, c);
         } else {
@@ -901,10 +909,6 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
     T.template load<NA>(io, tile0, r);
     issue(T);
     Tn.template load<NA>(io, tile0 + tstride, r);
-    // the first tile's rows travel while the tables are staged
-    cl_stage_block<ALG, C, TB, true>(Cd.b[K], lds, threadIdx.x, cl_probe_dir<C>(c));
-    __syncthreads();
-    stamp(0);
     for (long tile = tile0; tile < ntiles; tile += tstride) {
         if constexpr (K == 0) {
             asm volatile("" : "+v"(g0), "+v"(g1));
@@ -955,7 +959,11 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
 #pragma unroll
             for (int d = 0; d < D; ++d) gx[d] = 0.f;
             cl_mix<C, C, TB::W1T(0)>(gx, gy, ldsw);
-            if (Tc.valid) CL_GST8(io.plw_g1 + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, gx);
+            if (single) {
+                carry_a = f4{gx[0], gx[1], gx[2], gx[3]}; carry_b = f4{gx[4], gx[5], gx[6], gx[7]};
+            } else if (Tc.valid) {
+                CL_GST8(io.plw_g1 + (size_t)Tc.row * ROW + c * D, sc + r * SS + c * D, gx);
+            }
         } else if constexpr (MODE == MODE_EDGE) {
             if (io.gx[0]) {
                 float gx[D];
@@ -1063,8 +1071,11 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
         put_tile(accL, PT::pWL, C, 0, C);
         // per-channel sums over the rows of the wave: one MFMA with A = 1 adds the lane bits 4-5 (every lane receives
         // its column's sum), one DPP add the interleaved row pair (C = 8)
+        f4 sv[ClSums<RM::n>::kGroups];
+#pragma unroll
+        for (int gq = 0; gq < ClSums<RM::n>::kGroups; ++gq) sv[gq] = cl_ld4(sm.base + gq * (4 * 64 * kClWaves));
         static_for<0, RM::n>([&](auto idx) {
-            const f4 t = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, sm.template get<idx>(), f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const f4 t = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, sv[idx / 4][idx % 4], f4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             float s = t[0];
             if constexpr (C == 8) s += dpp_mov<0xB1>(s);
             if (q == 0 && (C == 16 || (lane & 1) == 0)) img[PT::pS + PT::off(idx) + c * PT::stride(idx)] = s;
@@ -1073,7 +1084,7 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
         // block k's slices start behind those of the blocks 0 .. k - 1 (kClSliceCap slices each)
         float* part = io.rl_partials + (K == 0 ? 0 : (size_t)kClSliceCap * ClPart<ALG, C, ClTab<C, MODE, NA, 0, true>::I>::total) +
                       (size_t)blockIdx.x * PT::total;
-        const float* img0 = lds + TB::total;
+        const float* img0 = work;
         static_assert(PT::total % 4 == 0, "slice length");
         for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kClWaves) {
             f4 v = cl_ld4(img0 + e);
@@ -1083,22 +1094,17 @@ CSMPN_DEV void cl_bwd_block(const DevCemlp& Cd, const RowIO& io, float* smem, Cl
         }
     }
     stamp(17);
-}
-template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-constexpr size_t cl_bwd_block_lds_bytes() {
-    using TB = ClTab<C, MODE, NA, K, true>;
-    using PT = ClPart<ALG, C, TB::I>;
-    constexpr int tile = ClMap<C>::RPW * (C * ALG::D + 4);
-    return sizeof(float) * (TB::total + kClWaves * (tile > PT::total ? tile : PT::total) + ClSums<ClRed<ALG>::n>::floats_per_wg);
+    return ClCarry{carry_a, carry_b};
 }
 template <class ALG, int C, int MODE, int NBLK, int NA>
 constexpr size_t cl_bwd_lds_bytes() {
-    size_t m = cl_bwd_block_lds_bytes<ALG, C, MODE, NBLK, NA, 0>();
-    if constexpr (NBLK > 1) {
-        constexpr size_t m1 = cl_bwd_block_lds_bytes<ALG, C, MODE, NBLK, NA, 1>();
-        if (m1 > m) m = m1;
-    }
-    return m;
+    using TB0 = ClTab<C, MODE, NA, 0, true>;
+    using TB1 = ClTab<C, MODE, NA, 1, true>;
+    constexpr int tile = ClMap<C>::RPW * (C * ALG::D + 4);
+    int img = ClPart<ALG, C, TB0::I>::total;
+    if (NBLK > 1 && ClPart<ALG, C, C>::total > img) img = ClPart<ALG, C, C>::total;
+    return sizeof(float) * (TB0::total + (NBLK > 1 ? TB1::total : 0) + kClWaves * (tile > img ? tile : img) +
+                            ClSums<ClRed<ALG>::n>::floats_per_wg);
 }
 // The backward kernel: the blocks one after the other (last block first) in ONE launch. A wave keeps its tiles from
 // block to block, so the hand-over rows d/d(block input) it reads in block k - 1 are the ones it wrote itself in block k
@@ -1115,41 +1121,64 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
     (void)C_arg; (void)io_arg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ClStamp stamp(0);
-    if constexpr (NBLK > 1) {
-        cl_bwd_block<ALG, C, MODE, NBLK, NA, 1>(Cd, io, smem, stamp);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
-        __syncthreads();                                   // ... and every wave is done with the LDS tables and images
+    using TB0 = ClTab<C, MODE, NA, 0, true>;
+    using TB1 = ClTab<C, MODE, NA, 1, true>;
+    constexpr int tabs = TB0::total + (NBLK > 1 ? TB1::total : 0);
+    // the tables of every block are staged up front (one prologue per launch)
+    {
+        const int dir = cl_probe_dir<C>(ClMap<C>::chan(threadIdx.x & 63));
+        cl_stage_block<ALG, C, TB0, true>(Cd.b[0], smem, threadIdx.x, dir);
+        if constexpr (NBLK > 1) cl_stage_block<ALG, C, TB1, true>(Cd.b[1], smem + TB0::total, threadIdx.x, dir);
     }
-    cl_bwd_block<ALG, C, MODE, NBLK, NA, 0>(Cd, io, smem, stamp);
+    __syncthreads();
+    stamp(0);
+    const long ntiles = (io.rows + ClMap<C>::RPW - 1) / ClMap<C>::RPW;
+    const bool single = ntiles <= (long)gridDim.x * kClWaves;   // one tile per wave: the hand-over stays in registers
+    ClCarry carry{f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (NBLK > 1) {
+        carry = cl_bwd_block<ALG, C, MODE, NBLK, NA, 1>(io, smem + TB0::total, smem + tabs, carry, single, stamp);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
+        __syncthreads();                                   // ... and every wave is done with the images
+    }
+    cl_bwd_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, smem + tabs, carry, single, stamp);
     stamp.flush(io.stamps, threadIdx.x & 63);
 }
 
-// last kernel of a backward: grads += sum over the workgroups' slices of EVERY block launch, fixed order
-// (deterministic). The slices of block k start at part + k * kSliceCap * (slice length of block 0 ... k - 1). One wave per
-// element: lane g adds the slices g, g + 64, ... (all loads in flight together), then a butterfly over the 64 lanes.
+// last kernel of a backward: grads += sum over the workgroups' slices of EVERY block, fixed order (deterministic).
+// The slices of block 1 start slice_cap * (slice length of block 0) floats behind those of block 0. A workgroup takes 16
+// consecutive elements (64-byte pieces of every slice); thread (j = tid & 15, w = tid >> 4) adds the slices w, w + 16,
+// ... sixteen loads in flight at a time; the 16 partial sums of an element meet in LDS and are added in order.
 template <class ALG, int C, int I0, int NBLK>
 __global__ void __launch_bounds__(256) cl_reduce_kernel(const DevCemlp Cd, const float* part, int nslices, int slice_cap) {
     constexpr int G = ALG::G;
     using P0 = ClPart<ALG, C, I0>;
     using P1 = ClPart<ALG, C, C>;
     constexpr int total = P0::total + (NBLK > 1 ? P1::total : 0);
-    const int g = threadIdx.x & 63;
-    int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (e >= total) return;   // whole waves leave together
+    __shared__ float red[16][17];
+    const int j = threadIdx.x & 15, w = threadIdx.x >> 4;
+    int e = blockIdx.x * 16 + j;
+    const bool live = e < total;
+    if (!live) e = 0;
     const int k = (NBLK > 1 && e >= P0::total) ? 1 : 0;
     const int len = k == 0 ? P0::total : P1::total;
     const float* p = part + (k == 0 ? 0 : (size_t)slice_cap * P0::total);
     if (k == 1) e -= P0::total;
-    float v[8];
+    float s = 0.f;
+    for (int s0 = w; s0 < nslices; s0 += 256) {
+        float v[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int sl = g + 64 * i;
-        v[i] = sl < nslices ? p[(size_t)sl * len + e] : 0.f;
+        for (int i = 0; i < 16; ++i) {
+            const int sl = s0 + 16 * i;
+            v[i] = sl < nslices ? p[(size_t)sl * len + e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += v[i];
     }
-    float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    red[w][j] = s;
+    __syncthreads();
+    if (w != 0 || !live) return;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (g != 0) return;
+    for (int i = 1; i < 16; ++i) s += red[i][j];
     const DevBlock& B = Cd.b[k];
     const int I = k == 0 ? I0 : C;
     int f = e;
