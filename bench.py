@@ -14,11 +14,11 @@ on synthetic input already resident in HBM.
 Workload (BASELINE.json configs[1]): S1 = Cl(3,0), 8 channels,
 10 000 nodes, 100 000 directed adjacencies per GPU, aggr=mean, seeded generator.
 With N > 1 GPUs the adjacency list of an N x 100k-edge complex over the same 10k nodes is
-sharded (100k edges per rank, weak scaling). Default partitioning B (csmpn_hip/sharded.py): every
-rank owns N/W nodes and all edges into them - all-gather of the updated node slices forward,
-reduce-scatter of d/dh backward, all-reduce of the parameter gradients; `--partition A` = contiguous
+sharded (100k edges per rank, weak scaling). Default partitioning A (BASELINE.json's wording): contiguous
 edge shards with an all-reduce of the per-node aggregate (forward) and of [d/dh | edge-model
-gradients] (backward). `--scaling strong --workload S2` shards ONE 1M-edge complex (north_star's
+gradients] (backward). `--partition B` (csmpn_hip/sharded.py): every rank owns a node slice (cut by
+in-degree) and all edges into it - all-gather of the updated node slices forward, reduce-scatter of
+d/dh backward, all-reduce of the parameter gradients. `--scaling strong --workload S2` shards ONE 1M-edge complex (north_star's
 multi-GPU configuration) instead and also reports the compute-only rate and the bus bandwidth.
 """
 import argparse
@@ -190,8 +190,9 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = the workload's edges PER rank; strong = ONE complex sharded over the ranks")
-    ap.add_argument("--partition", default="B", choices=["A", "B"],
-                    help="N > 1: B = destination-partitioned (all-gather / reduce-scatter), A = edge shards (all-reduce)")
+    ap.add_argument("--partition", default="A", choices=["A", "B"],
+                    help="N > 1: A = edge shards + all-reduce of the per-node aggregate (BASELINE.json's wording, the "
+                         "default); B = destination-partitioned (all-gather / reduce-scatter; never yet measured on RCCL)")
     ap.add_argument("--deterministic", action="store_true",
                     help="atomic-free aggregation (CSMPN_FLAG_DETERMINISTIC): edge rows to a table + fixed-order segmented sums")
     args = ap.parse_args()
@@ -202,6 +203,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: the line would report a wrong n_gpus")
     import torch.distributed as dist
     # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer
     # GPUs than ranks (--dist-backend gloo: RCCL refuses two ranks on one device)
@@ -291,7 +293,14 @@ def main():
     for _ in range(2):
         run()
 
+    edges_per_rank = None
     if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        cnt = torch.zeros(world, dtype=torch.int64, device=device)
+        cnt[rank] = int(plan.csr.n_edges)
+        dist.all_reduce(cnt)
+        edges_per_rank = cnt.tolist()
+        assert sum(edges_per_rank) == E_total, (edges_per_rank, E_total)   # every adjacency on exactly one rank
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -397,6 +406,7 @@ def main():
                                     "B: nodes partitioned, edges by target; all-gather(out) fwd, reduce-scatter(d/dh) + "
                                     "all-reduce(param grads) bwd" if part_b else
                                     "A: edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"),
+                       "edges_per_rank": edges_per_rank,
                        "compute_only": compute_only},
             "roofline": roofline,
         }

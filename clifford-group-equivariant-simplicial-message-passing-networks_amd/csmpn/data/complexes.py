@@ -186,7 +186,13 @@ class SimplicialBatch:
             rows = torch.nonzero(self.node_types == d, as_tuple=False).flatten()
             perms = torch.tensor(list(itertools.permutations(range(d + 1))), device=rows.device)
             plan["rows"].append(rows)
-            plan["verts"].append(vrows[rows][:, : d + 1][:, perms].reshape(-1, d + 1).contiguous())
+            vt = vrows[rows][:, : d + 1]
+            # once per batch (the kernel clamps out-of-range rows instead of faulting: check here, where PyTorch
+            # indexing would have asserted)
+            if vt.numel() and (int(vt.min()) < 0 or int(vt.max()) >= int(self.node_types.shape[0])):
+                raise IndexError(f"x_ind of the {d}-simplices points outside the batch ({int(vt.min())}..{int(vt.max())} "
+                                 f"of {int(self.node_types.shape[0])} rows)")
+            plan["verts"].append(vt[:, perms].reshape(-1, d + 1).contiguous())
             plan["nperm"].append(int(perms.shape[0]))
         plan["vertex_rows"] = plan["rows"][0]
         plan["graph_of_vertex"] = self.batch[plan["rows"][0]]

@@ -277,6 +277,15 @@ def _soft_fallback(rc):
     return True
 
 
+def _warn_soft_slice():
+    global _warned_soft_det
+    if not _warned_soft_det:
+        _warned_soft_det = True
+        warnings.warn("csmpn_hip: torch.use_deterministic_algorithms(True) is set, but this launch covers a slice of "
+                      "the adjacency (graph-segment step): using float atomics (ops.set_deterministic(True) makes "
+                      "this an error)")
+
+
 def segment_reduce(rows, out, add=None, sub=None, accumulate=True):
     """out[v] (+)= sum rows[add segment of v] - sum rows[sub segment of v] in a fixed order.
     add / sub: (row_ptr, order or None) int32 device tensors."""
@@ -401,10 +410,15 @@ class HipBackend:
         if saved is None and save:
             saved = e.new_saved(csr.n_edges, h.device)
         det = deterministic_request()
-        if det:
-            if not isinstance(csr, Csr):
+        if det and not isinstance(csr, Csr):
+            # a slice of the adjacency (graph-segment steps): only an explicit request is an error; the inherited
+            # torch.use_deterministic_algorithms(True) of the reference's seeding warns once and keeps the atomics
+            if det == "hard":
                 raise native.CsmpnError("deterministic aggregation needs the whole adjacency (no sliced launches: "
                                         "set CSMPN_SPLIT_FWD=0)")
+            _warn_soft_slice()
+            det = None
+        if det:
             rows = torch.empty(max(csr.n_edges, 1), spec.O, D, dtype=torch.float32, device=h.device)
             rc = native.lib().csmpn_egcl_edge_forward(
                 e.metric_arr, e.n, e.params, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
@@ -483,9 +497,12 @@ class HipBackend:
         ws, saved = state if state is not None else (e.workspace(dev), None)
         flags = native.FLAG_WEIGHTS_PACKED if state is not None else 0
         det = deterministic_request()
-        if det:
-            if not isinstance(csr, Csr):
+        if det and not isinstance(csr, Csr):
+            if det == "hard":
                 raise native.CsmpnError("deterministic aggregation needs the whole adjacency (no sliced launches)")
+            _warn_soft_slice()
+            det = None
+        if det:
             rows = torch.empty(max(csr.n_edges, 1), spec.C, e.D, dtype=torch.float32, device=dev)
             rc = native.lib().csmpn_egcl_edge_backward(
                 e.metric_arr, e.n, e.params, e.grads, e.nblk, h.data_ptr(), spec.C, _ptr(edge_attr), spec.A,
@@ -822,7 +839,7 @@ def geometric_product_apply(a, b, metric):
 # --------------------------------------------------------------------------------- callers either side (SURVEY §8(f)-1,2)
 
 
-@_on_device_of(1)
+@_on_device_of(2)
 def simplex_rows(n: int, blocks, verts: torch.Tensor) -> torch.Tensor:
     """Input rows of the simplex feature embedding (csmpn_simplex_rows). blocks: [(tensor [S, K, n_g], grade)],
     verts [rows, d+1] int64 batch rows of the vertices in one vertex order. The feature tensors are data

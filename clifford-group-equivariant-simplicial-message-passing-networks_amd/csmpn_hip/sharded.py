@@ -265,11 +265,29 @@ class GraphedShardedStep:
 
 
 def node_bounds(n_nodes: int, world: int, rank: int):
-    """Equal node slices (reduce-scatter / all-gather need equal sizes): N must divide by the world size."""
-    if n_nodes % world:
-        raise ValueError(f"partitioning B needs n_nodes ({n_nodes}) divisible by the world size ({world})")
-    per = n_nodes // world
-    return rank * per, (rank + 1) * per
+    """Equal-width node slice of `rank` (the last slices are one shorter when N does not divide by the world size)."""
+    base, rem = divmod(n_nodes, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def balanced_node_cuts(in_degree: torch.Tensor, world: int):
+    """W + 1 cut points of the node range such that every slice receives about E / W adjacencies (prefix sum of the
+    in-degree): the edge stage is the expensive one, so slices are balanced by incoming edges, not by node count. A hub
+    may leave a slice empty; cuts are non-decreasing and cover [0, N]."""
+    n = int(in_degree.shape[0])
+    if world == 1:
+        return [0, n]
+    csum = torch.cumsum(in_degree.to(torch.int64).cpu(), 0)
+    total = int(csum[-1]) if n else 0
+    if total == 0:
+        return [node_bounds(n, world, r)[0] for r in range(world)] + [n]
+    targets = torch.tensor([total * r // world for r in range(1, world)], dtype=torch.int64)
+    inner = torch.searchsorted(csum, targets, right=False).tolist()   # first node whose prefix reaches the target
+    cuts = [0] + [min(max(int(c), 0), n) for c in inner] + [n]
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
 
 
 def _world(group):
@@ -278,20 +296,27 @@ def _world(group):
     return 1, 0
 
 
+def _fused_collectives(group) -> bool:
+    """The single-tensor collectives (all_gather_into_tensor / reduce_scatter_tensor) exist on NCCL = RCCL; gloo takes the
+    list / all-reduce forms. Decided ONCE from the backend name: a per-call try / except would let a rank-local
+    error (an OOM, an asynchronous failure) send one rank to a different collective than its peers."""
+    return "nccl" in str(dist.get_backend(group)).lower()
+
+
 def _all_gather_rows(full, part, group):
     """full[W * n] <- concat over ranks of part[n] (rows)."""
-    try:
+    if _fused_collectives(group):
         dist.all_gather_into_tensor(full, part, group=group)
-    except (RuntimeError, NotImplementedError):   # backends without the fused form (gloo on old builds)
+    else:
         chunks = list(full.chunk(dist.get_world_size(group), dim=0))
         dist.all_gather(chunks, part, group=group)
 
 
 def _reduce_scatter_rows(part, full, group):
     """part[n] <- this rank's row slice of the sum over ranks of full[W * n]."""
-    try:
+    if _fused_collectives(group):
         dist.reduce_scatter_tensor(part, full, op=dist.ReduceOp.SUM, group=group)
-    except (RuntimeError, NotImplementedError):   # gloo has no reduce-scatter: all-reduce and slice
+    else:   # gloo has no reduce-scatter: all-reduce and slice
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
         w, r = dist.get_world_size(group), dist.get_rank(group)
         part.copy_(full.chunk(w, dim=0)[r])
@@ -308,55 +333,109 @@ def agree_all(local_ok: bool, group=None, device=None) -> bool:
 
 
 class DstPlan:
-    """Per-complex state of one rank for partitioning B: the edges into its node slice (global node
-    ids), their ids in the caller's edge order (for edge_attr), and the slice bounds."""
+    """Per-complex state of one rank for partitioning B: the edges into its node slice (global node ids), their ids in
+    the caller's edge order (for edge_attr), the slice cuts of every rank (balanced by in-degree unless `balance=False`)
+    and the index tables that move rows between the natural layout [N] and the padded layout [W * per] the
+    equal-size collectives need (per = longest slice; pad rows read a zero row / are dropped)."""
 
-    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None):
+    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None, balance=True):
         self.world, self.rank = _world(group)
-        self.lo, self.hi = node_bounds(n_nodes, self.world, self.rank)
+        dev = edge_index.device
         dst = edge_index[1]
+        if balance and self.world > 1:
+            deg_all = torch.bincount(dst, minlength=n_nodes)
+            self.cuts = balanced_node_cuts(deg_all, self.world)
+        else:
+            self.cuts = [node_bounds(n_nodes, self.world, r)[0] for r in range(self.world)] + [n_nodes]
+        self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
+        self.per = max(1, max(self.cuts[r + 1] - self.cuts[r] for r in range(self.world)))
         mine = (dst >= self.lo) & (dst < self.hi)
         self.edge_ids = torch.nonzero(mine, as_tuple=False).squeeze(1)
         self.csr = backend.build_csr(edge_index[:, self.edge_ids].contiguous(), n_nodes)
         self.deg = self.csr.deg     # every edge into an owned node is local: the local in-degree is the global one
         self.n_nodes = n_nodes
+        # padded position of every node row / node row (or N = the zero row) of every padded position
+        pos = torch.empty(n_nodes, dtype=torch.int64)
+        src = torch.full((self.world * self.per,), n_nodes, dtype=torch.int64)
+        for r in range(self.world):
+            lo, hi = self.cuts[r], self.cuts[r + 1]
+            pos[lo:hi] = torch.arange(r * self.per, r * self.per + (hi - lo))
+            src[r * self.per: r * self.per + (hi - lo)] = torch.arange(lo, hi)
+        self.pos_of_node = pos.to(dev)
+        self.node_of_pos = src.to(dev)
+        self.edges_per_rank = None
+        if self.world > 1:
+            cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            cnt[self.rank] = int(self.edge_ids.numel())
+            dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+            self.edges_per_rank = cnt.tolist()
+
+    # ---- rows between the layouts (one index kernel each)
+    def pad_slice(self, rows_loc):
+        """[hi - lo, ...] -> [per, ...] (zero pad rows)."""
+        n = self.hi - self.lo
+        if n == self.per:
+            return rows_loc.contiguous()
+        out = rows_loc.new_zeros((self.per,) + tuple(rows_loc.shape[1:]))
+        out[:n] = rows_loc
+        return out
+
+    def to_padded(self, rows_all):
+        """[N, ...] -> [W * per, ...] (pad positions zero): the input layout of the reduce-scatter."""
+        z = torch.cat([rows_all, rows_all.new_zeros((1,) + tuple(rows_all.shape[1:]))], dim=0)
+        return z.index_select(0, self.node_of_pos)
+
+    def from_padded(self, padded):
+        """[W * per, ...] -> [N, ...]: the output layout of the all-gather."""
+        return padded.index_select(0, self.pos_of_node)
 
 
-class _DstPartEgclFn(torch.autograd.Function):
-    """h [N, C, D] replicated in; out [N, C, D] replicated out (all-gathered); gradients w.r.t. h
-    come back replicated as well (reduce-scatter + all-gather of the slices), so the layer composes
-    like the unsharded one."""
+class _DstPartStackFn(torch.autograd.Function):
+    """L chained EGCL layers, destination-partitioned. h [N, C, D] replicated in, the last layer's output replicated out.
+    Forward, per layer: edge stage on the owned edges -> node update of the owned slice -> ONE all-gather. Backward, per
+    layer: node backward on the slice -> edge backward on the owned edges -> ONE reduce-scatter of d/dh, whose result
+    (+ the node stage's d/dh) is exactly the slice of d/d(previous layer's output) the next step needs - no all-gather
+    between chained layers; the replicated d/dh of the chain's input is all-gathered once, if anybody asks for it. The
+    parameter gradients of all layers travel in ONE all-reduce."""
 
     @staticmethod
-    def forward(ctx, h, edge_attr_local, node_attr, spec, plan: DstPlan, backend, group, *params):
-        h = h.contiguous()
-        ne = spec.edge.nblk * ops.NP
-        pe, pn = params[:ne], params[ne:]
+    def forward(ctx, h, edge_attr_local, node_attr, specs, plan: DstPlan, backend, group, counts, *params):
         lo, hi = plan.lo, plan.hi
-        agg, st_e = backend.edge_forward(spec, plan.csr, h, edge_attr_local, pe)      # complete on [lo, hi)
         na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
-        out_loc, st_n = backend.node_forward(spec, plan.deg[lo:hi].contiguous(), h[lo:hi].contiguous(),
-                                             agg[lo:hi].contiguous(), na_loc, pn)
-        if plan.world > 1:
-            out = torch.empty_like(h) if out_loc.shape[1:] == h.shape[1:] else \
-                torch.empty((h.shape[0],) + tuple(out_loc.shape[1:]), dtype=h.dtype, device=h.device)
-            _all_gather_rows(out, out_loc.contiguous(), group)
-        else:
-            out = out_loc
-        ctx.st_e, ctx.st_n = st_e, st_n
-        ctx.spec, ctx.plan, ctx.backend, ctx.group = spec, plan, backend, group
+        deg_loc = plan.deg[lo:hi].contiguous()
+        hs, aggs, st = [], [], []
+        x = h.contiguous()
+        off = 0
+        for spec, cnt in zip(specs, counts):
+            lp = params[off:off + cnt]
+            off += cnt
+            ne = spec.edge.nblk * ops.NP
+            pe, pn = lp[:ne], lp[ne:]
+            agg, st_e = backend.edge_forward(spec, plan.csr, x, edge_attr_local, pe)      # complete on [lo, hi)
+            out_loc, st_n = backend.node_forward(spec, deg_loc, x[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn)
+            hs.append(x); aggs.append(agg); st.append((st_e, st_n))
+            if plan.world > 1:
+                padded = out_loc.new_empty((plan.world * plan.per,) + tuple(out_loc.shape[1:]))
+                _all_gather_rows(padded, plan.pad_slice(out_loc), group)
+                x = plan.from_padded(padded)
+            else:
+                x = out_loc
+        ctx.st = st
+        ctx.specs, ctx.plan, ctx.backend, ctx.group, ctx.counts = specs, plan, backend, group, counts
         ctx.has_ea, ctx.has_na = edge_attr_local is not None, node_attr is not None
         ctx.mask = [p is not None for p in params]
-        saved = [h, agg] + ([edge_attr_local] if ctx.has_ea else []) + ([node_attr] if ctx.has_na else [])
+        ctx.n_layers = len(specs)
+        saved = hs + aggs + ([edge_attr_local] if ctx.has_ea else []) + ([node_attr] if ctx.has_na else [])
         ctx.save_for_backward(*saved, *[p for p in params if p is not None])
-        return out
+        return x
 
     @staticmethod
     def backward(ctx, gout):
-        spec, plan, backend, group = ctx.spec, ctx.plan, ctx.backend, ctx.group
+        specs, plan, backend, group, counts = ctx.specs, ctx.plan, ctx.backend, ctx.group, ctx.counts
+        L = ctx.n_layers
         saved = list(ctx.saved_tensors)
-        h, agg = saved[0], saved[1]
-        pos = 2
+        hs, aggs = saved[:L], saved[L:2 * L]
+        pos = 2 * L
         edge_attr = node_attr = None
         if ctx.has_ea:
             edge_attr = saved[pos]; pos += 1
@@ -364,45 +443,74 @@ class _DstPartEgclFn(torch.autograd.Function):
             node_attr = saved[pos]; pos += 1
         it = iter(saved[pos:])
         params = [next(it) if m else None for m in ctx.mask]
-        ne = spec.edge.nblk * ops.NP
-        pe, pn = params[:ne], params[ne:]
         lo, hi = plan.lo, plan.hi
         na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
-        gh_node, g_agg_loc, g_na_loc, views_n = backend.node_backward(
-            spec, plan.deg[lo:hi].contiguous(), h[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn,
-            gout[lo:hi].contiguous(), ctx.needs_input_grad[2], ctx.st_n)
-        g_agg = torch.zeros_like(agg)
-        g_agg[lo:hi] = g_agg_loc
-        gh_edge = torch.zeros_like(h)          # +g -> owned targets, -g -> any source
-        g_ea, views_e = backend.edge_backward(spec, plan.csr, h, edge_attr, pe, g_agg, gh_edge,
-                                              ctx.needs_input_grad[1], ctx.st_e)
-        views = list(views_e) + list(views_n)
-        if plan.world > 1:
-            gh_loc = torch.empty_like(gh_node)
-            _reduce_scatter_rows(gh_loc, gh_edge, group)
-            gh_loc += gh_node
-            gh = torch.empty_like(h)
-            _all_gather_rows(gh, gh_loc, group)
-            flat = torch.cat([v.reshape(-1) for v in views if v is not None])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            off, red = 0, []
-            for v in views:
-                if v is None:
-                    red.append(None)
-                else:
-                    red.append(flat[off:off + v.numel()].view(v.shape))
-                    off += v.numel()
-            views = red
-            g_na = None
+        deg_loc = plan.deg[lo:hi].contiguous()
+        offs = [0]
+        for cnt in counts:
+            offs.append(offs[-1] + cnt)
+        g_loc = gout[lo:hi].contiguous()          # d/d(output slice) of the layer being processed
+        views_all = [None] * len(params)
+        g_ea_total, g_na_loc_total = None, None
+        gh_full_single = None
+        for k in range(L - 1, -1, -1):
+            spec = specs[k]
+            lp = params[offs[k]:offs[k + 1]]
+            ne = spec.edge.nblk * ops.NP
+            pe, pn = lp[:ne], lp[ne:]
+            h, agg = hs[k], aggs[k]
+            st_e, st_n = ctx.st[k]
+            gh_node, g_agg_loc, g_na_loc, views_n = backend.node_backward(
+                spec, deg_loc, h[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn, g_loc,
+                ctx.needs_input_grad[2], st_n)
+            g_agg = torch.zeros_like(agg)
+            g_agg[lo:hi] = g_agg_loc
+            gh_edge = torch.zeros_like(h)          # +g -> owned targets, -g -> any source
+            g_ea, views_e = backend.edge_backward(spec, plan.csr, h, edge_attr, pe, g_agg, gh_edge,
+                                                  ctx.needs_input_grad[1], st_e)
+            for i, v in enumerate(list(views_e) + list(views_n)):
+                views_all[offs[k] + i] = v
+            if g_ea is not None:
+                g_ea_total = g_ea if g_ea_total is None else g_ea_total + g_ea
             if g_na_loc is not None:
+                g_na_loc_total = g_na_loc if g_na_loc_total is None else g_na_loc_total + g_na_loc
+            if plan.world > 1:
+                g_pad = gh_edge.new_empty((plan.per,) + tuple(gh_edge.shape[1:]))
+                _reduce_scatter_rows(g_pad, plan.to_padded(gh_edge), group)
+                g_loc = g_pad[:hi - lo] + gh_node
+            else:
+                gh_edge[lo:hi] += gh_node
+                gh_full_single = gh_edge
+                g_loc = gh_edge[lo:hi]
+        gh = None
+        if ctx.needs_input_grad[0]:
+            if plan.world > 1:
+                padded = g_loc.new_empty((plan.world * plan.per,) + tuple(g_loc.shape[1:]))
+                _all_gather_rows(padded, plan.pad_slice(g_loc), group)
+                gh = plan.from_padded(padded)
+            else:
+                gh = gh_full_single
+        g_na = None
+        if plan.world > 1:
+            live = [v for v in views_all if v is not None]
+            if live:
+                flat = torch.cat([v.reshape(-1) for v in live])
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+                off, red = 0, []
+                for v in views_all:
+                    if v is None:
+                        red.append(None)
+                    else:
+                        red.append(flat[off:off + v.numel()].view(v.shape))
+                        off += v.numel()
+                views_all = red
+            if g_na_loc_total is not None:
                 g_na = torch.zeros_like(node_attr)
-                g_na[lo:hi] = g_na_loc
+                g_na[lo:hi] = g_na_loc_total
                 dist.all_reduce(g_na, op=dist.ReduceOp.SUM, group=group)
         else:
-            gh = gh_edge
-            gh[lo:hi] += gh_node
-            g_na = g_na_loc
-        return (gh, g_ea, g_na, None, None, None, None, *views)
+            g_na = g_na_loc_total
+        return (gh, g_ea_total, g_na, None, None, None, None, None, *views_all)
 
 
 class DstPartitionedEGCL(torch.nn.Module):
@@ -410,27 +518,55 @@ class DstPartitionedEGCL(torch.nn.Module):
     (replicated topology); forward takes the whole h / node_attr and this rank's rows of edge_attr
     (`edge_attr[plan.edge_ids]`)."""
 
-    def __init__(self, layer, backend=ops.HipBackend, group=None):
+    def __init__(self, layer, backend=ops.HipBackend, group=None, balance=True):
         super().__init__()
         self.layer = layer
         self.backend = backend
         self.group = group
+        self.balance = balance
 
     def plan(self, edge_index, n_nodes) -> DstPlan:
-        return DstPlan(edge_index, n_nodes, self.backend, self.group)
+        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance)
 
     def forward(self, h, plan: DstPlan, edge_attr_local=None, node_attr=None):
         layer = self.layer
         params = layer.edge_model.flat_params() + layer.node_model.flat_params()
-        return _DstPartEgclFn.apply(h, edge_attr_local, node_attr, layer.spec(), plan, self.backend, self.group,
-                                    *params)
+        return _DstPartStackFn.apply(h, edge_attr_local, node_attr, (layer.spec(),), plan, self.backend, self.group,
+                                     (len(params),), *params)
+
+
+class DstPartitionedStack(torch.nn.Module):
+    """L chained EGCL layers on ONE destination partition of the complex: h stays resident, every
+    layer costs one all-gather forward and one reduce-scatter backward, the parameter gradients of all layers one
+    all-reduce. All layers share edge_attr / node_attr, as the reference's models do (hulls_cssmpnn.py:89-94)."""
+
+    def __init__(self, layers, backend=ops.HipBackend, group=None, balance=True):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(layers)
+        self.backend = backend
+        self.group = group
+        self.balance = balance
+
+    def plan(self, edge_index, n_nodes) -> DstPlan:
+        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance)
+
+    def forward(self, h, plan: DstPlan, edge_attr_local=None, node_attr=None):
+        params, counts, specs = [], [], []
+        for layer in self.layers:
+            lp = layer.edge_model.flat_params() + layer.node_model.flat_params()
+            params += lp
+            counts.append(len(lp))
+            specs.append(layer.spec())
+        return _DstPartStackFn.apply(h, edge_attr_local, node_attr, tuple(specs), plan, self.backend, self.group,
+                                     tuple(counts), *params)
 
 
 class GraphedDstStep:
     """Forward + backward of the destination-partitioned layer on fixed buffers (multi-GPU benchmark):
-    [graph 1: edge forward on the owned targets, node forward on the owned nodes] -> all-gather(out)
-    -> [graph 2: node backward, edge backward] -> reduce-scatter(d/dh) + all-reduce(parameter
-    gradients). `compute_only=True` skips the collectives (the compute-only rate of the bench)."""
+    [graph 1: edge forward on the owned targets, node forward on the owned nodes, slice padded] -> all-gather(out)
+    -> [graph 2: rows back to the natural layout, node backward, edge backward, d/dh rows to the padded layout] ->
+    reduce-scatter(d/dh) + all-reduce(parameter gradients). `compute_only=True` skips the collectives (the
+    compute-only rate of the bench)."""
 
     def __init__(self, part: "DstPartitionedEGCL", plan: DstPlan, h, edge_attr_local, node_attr, gout):
         layer, be = part.layer, part.backend
@@ -442,22 +578,22 @@ class GraphedDstStep:
         self._multi = plan.world > 1
         na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
         h_loc, deg_loc, gout_loc = h_[lo:hi], plan.deg[lo:hi].contiguous(), gout[lo:hi].contiguous()
-        self.out = torch.empty_like(h_)
-        self.gh = torch.empty_like(h_)
+        self.out_all = h_.new_empty((plan.world * plan.per,) + tuple(h_.shape[1:]))   # all-gather target (padded layout)
 
         def part1():
             agg, st_e = be.edge_forward(spec, plan.csr, h_, edge_attr_local, pe)
             out_loc, st_n = be.node_forward(spec, deg_loc, h_loc, agg[lo:hi], na_loc, pn)
-            return agg, st_e, out_loc, st_n
+            return agg, st_e, plan.pad_slice(out_loc), st_n
 
         def part2(agg, st_e, st_n):
+            out = plan.from_padded(self.out_all) if self._multi else None   # the layer's replicated output
             gh_node, g_agg_loc, _g, views_n = be.node_backward(spec, deg_loc, h_loc, agg[lo:hi], na_loc, pn, gout_loc, False, st_n)
             g_agg = torch.zeros_like(agg)
             g_agg[lo:hi] = g_agg_loc
             gh_edge = torch.zeros_like(h_)
             _g_ea, views_e = be.edge_backward(spec, plan.csr, h_, edge_attr_local, pe, g_agg, gh_edge, False, st_e)
             flat = torch.cat([v.reshape(-1) for v in list(views_e) + list(views_n) if v is not None])
-            return gh_node, gh_edge, flat
+            return gh_node, gh_edge, plan.to_padded(gh_edge) if self._multi else None, flat, out
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -468,24 +604,26 @@ class GraphedDstStep:
         torch.cuda.synchronize()
         self.g1, self.g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g1, capture_error_mode="thread_local"):
-            self.agg, self._st_e, self.out_loc, self._st_n = part1()
+            self.agg, self._st_e, self.out_pad, self._st_n = part1()
         with torch.cuda.graph(self.g2, pool=self.g1.pool(), capture_error_mode="thread_local"):
-            self.gh_node, self.gh_edge, self.flat = part2(self.agg, self._st_e, self._st_n)
+            self.gh_node, self.gh_edge, self.gh_pad, self.flat, self.out = part2(self.agg, self._st_e, self._st_n)
+        self.gh_rs = h_.new_empty((plan.per,) + tuple(h_.shape[1:]))   # reduce-scatter target: this rank's padded slice
         self.gh_loc = torch.empty_like(self.gh_node)
         self.bytes_per_step = 0
         if self._multi:
             w = plan.world
-            # bytes every rank sends per step: all-gather and reduce-scatter move (W-1)/W of the tensor
-            self.bytes_per_step = int(2 * h_.numel() * 4 * (w - 1) / w + 2 * self.flat.numel() * 4 * (w - 1) / w)
+            # bytes every rank sends per step: all-gather and reduce-scatter move (W-1)/W of the padded tensor
+            self.bytes_per_step = int(2 * w * plan.per * h_[0].numel() * 4 * (w - 1) / w + 2 * self.flat.numel() * 4 * (w - 1) / w)
 
     def run(self, compute_only=False):
         self.g1.replay()
         if self._multi and not compute_only:
-            _all_gather_rows(self.out, self.out_loc, self.group)
+            _all_gather_rows(self.out_all, self.out_pad, self.group)
         self.g2.replay()
+        n = self.plan.hi - self.plan.lo
         if self._multi and not compute_only:
-            _reduce_scatter_rows(self.gh_loc, self.gh_edge, self.group)
+            _reduce_scatter_rows(self.gh_rs, self.gh_pad, self.group)
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.gh_loc += self.gh_node
+            torch.add(self.gh_rs[:n], self.gh_node, out=self.gh_loc)
         else:
             torch.add(self.gh_edge[self.plan.lo:self.plan.hi], self.gh_node, out=self.gh_loc)

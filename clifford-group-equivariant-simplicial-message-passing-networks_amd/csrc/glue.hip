@@ -46,7 +46,7 @@ __global__ void simplex_rows_kernel(RowsDesc ds, const int64_t* verts, long n_ro
             const int td = d - ds.gstart[b];
             if (td >= 0 && td < ds.gsize[b]) {
                 long src = verts[r * ds.vpr + vert];
-                if (src < 0 || src >= n_feat_rows) src = 0;   // validated on the host side of the binding
+                if (src < 0 || src >= n_feat_rows) src = 0;   // out of range: validated once per batch on the host (SimplicialBatch.plan)
                 v = ds.data[b][(src * ds.channels[b] + k) * ds.gsize[b] + td];
             }
         }

@@ -114,13 +114,15 @@ def _worker_dst(rank, world, port, aggr, q):
         alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
         layer = pkg.EGCL(alg, 4, 5, 4, edge_attr_features=6, node_attr_features=3, aggr=aggr)
         o = O.Algebra([1.0, 1.0, 1.0])
-        N, E = 12 * world, 401
+        N, E = 12 * world + 1, 401           # N does not divide by the world size
         h, ei, ea, na = O.synthetic_complex(o, N, E, 4, seed=1)
-        ei[1, :40] = 3                       # a hub inside rank 0's slice: unbalanced edge counts
+        ei[1, :40] = 3                       # a hub: slices are cut by in-degree, not by node count
         gout = torch.randn(N, 4, 8, generator=torch.Generator().manual_seed(2))
         part = sharded.DstPartitionedEGCL(layer, backend=OracleBackend)
         plan = part.plan(ei, N)
-        assert plan.hi - plan.lo == N // world
+        assert plan.cuts[0] == 0 and plan.cuts[-1] == N and sorted(plan.cuts) == plan.cuts
+        assert sum(plan.edges_per_rank) == E
+        assert max(plan.edges_per_rank) <= E // world + 40 + N   # balanced by incoming edges (the hub is indivisible)
         hh = h.clone().requires_grad_(True)
         eal = ea[plan.edge_ids].clone().requires_grad_(True)
         naa = na.clone().requires_grad_(True)
@@ -164,6 +166,84 @@ def test_dst_partitioned_matches_unsharded(aggr, world):
         assert res["cover"] == 0
         for k, v in res.items():
             assert v < 5e-5, (rank, k, v)
+
+
+def _worker_stack(rank, world, port, q):
+    """Three chained layers on one destination partition: output, d/dh, attribute and every
+    parameter gradient equal the unsharded chain; N not divisible by the world size, a hub node, an isolated node."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        from oracle import ref_path as O
+        from oracle_backend import OracleBackend
+        torch.manual_seed(0)
+        alg = pkg.CliffordAlgebra((1.0, 1.0, 1.0))
+        layers = [pkg.EGCL(alg, 4, 5, 4, edge_attr_features=6, node_attr_features=3, aggr=a) for a in ("mean", "sum", "mean")]
+        o = O.Algebra([1.0, 1.0, 1.0])
+        N, E = 10 * world + 3, 333
+        h, ei, ea, na = O.synthetic_complex(o, N, E, 4, seed=3)
+        ei[1, :60] = N - 2                   # hub near the end
+        ei[:, ei[1] == 5] = torch.tensor([[1], [6]])   # node 5 receives nothing (isolated as a target)
+        gout = torch.randn(N, 4, 8, generator=torch.Generator().manual_seed(4))
+        stack = sharded.DstPartitionedStack(layers, backend=OracleBackend)
+        plan = stack.plan(ei, N)
+        hh = h.clone().requires_grad_(True)
+        eal = ea[plan.edge_ids].clone().requires_grad_(True)
+        naa = na.clone().requires_grad_(True)
+        y = stack(hh, plan, eal, naa)
+        y.backward(gout)
+        ps = [{k: v.detach().clone().requires_grad_(True) for k, v in l.named_parameters()} for l in layers]
+        h2 = h.clone().requires_grad_(True)
+        ea2 = ea.clone().requires_grad_(True)
+        na2 = na.clone().requires_grad_(True)
+        x = h2
+        for l, p, a in zip(layers, ps, ("mean", "sum", "mean")):
+            x = O.egcl(o, x, ei, ea2, na2, p, aggr=a)
+        x.backward(gout)
+        res = {"y": (y.detach() - x.detach()).abs().max().item() / x.detach().abs().max().item(),
+               "gh": (hh.grad - h2.grad).abs().max().item() / h2.grad.abs().max().item(),
+               "gea": (eal.grad - ea2.grad[plan.edge_ids]).abs().max().item() / ea2.grad.abs().max().item(),
+               "gna": (naa.grad - na2.grad).abs().max().item() / na2.grad.abs().max().item()}
+        for i, (l, p) in enumerate(zip(layers, ps)):
+            for k, prm in l.named_parameters():
+                res[f"g{i}." + k] = (prm.grad - p[k].grad).abs().max().item() / max(p[k].grad.abs().max().item(), 1e-6)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dst_partitioned_stack_matches_unsharded_chain(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stack, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        for k, v in res.items():
+            assert v < 1e-4, (rank, k, v)
+
+
+def test_balanced_node_cuts():
+    sys.path.insert(0, ROOT)
+    importlib.import_module(PKG)
+    from csmpn_hip import sharded
+    deg = torch.tensor([0, 5, 5, 0, 50, 1, 1, 1, 1, 0])
+    for w in (1, 2, 3, 4, 8):
+        cuts = sharded.balanced_node_cuts(deg, w)
+        assert len(cuts) == w + 1 and cuts[0] == 0 and cuts[-1] == 10 and cuts == sorted(cuts)
+    assert sharded.balanced_node_cuts(torch.zeros(7, dtype=torch.int64), 3) == [0, 3, 5, 7]
+    spans = [sharded.node_bounds(11, 4, r) for r in range(4)]
+    assert spans[0][0] == 0 and spans[-1][1] == 11 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
 def _worker_agree(rank, world, port, q):

@@ -148,3 +148,70 @@ def test_dst_partitioned_hip_matches_unsharded(metric, C):
     for rank, res in results:
         for k, v in res.items():
             assert v < 2e-5, (rank, k, v)
+
+
+# ----------------------------------------------------------------------------- data parallel over graphs
+
+def _worker_ddp(rank, world, port, q):
+    """The reference's multi-GPU mode (csmpn/md17.py:15-20, engineer/trainer/trainer.py:342-343): whole-model
+    DistributedDataParallel, every rank on its own graphs. Here: the md17 task model on the HIP layers, two ranks on
+    cuda:0 over gloo; the averaged gradients equal the single-process gradients of the mean of the two losses."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        pkg = importlib.import_module(PKG)
+        import test_model_harness as H
+        dev = torch.device("cuda:0")
+        g = np.load(os.path.join(ROOT, "tests", "golden", "model_md17.npz"))
+        model = H.build(pkg, "md17", g, dev)
+        batch = H.load_batch(pkg, g, device=dev)
+        # two different batches of the same topology: the fixture's batch, and the same complexes with perturbed positions
+        torch.manual_seed(7)
+        second = {k: getattr(batch, k) for k in batch._names}
+        for k in ("loc", "vel", "y"):
+            second[k] = second[k] + 0.05 * torch.randn_like(second[k])
+        batches = [batch, type(batch)(**second)]
+        # single process, both batches
+        model.zero_grad(set_to_none=True)
+        total = 0.0
+        for b in batches:
+            loss, _ = model(b)
+            (loss / world).backward()
+            total += float(loss.detach()) / world
+        ref = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        # data parallel: this rank's batch only
+        model.zero_grad(set_to_none=True)
+        ddp = torch.nn.parallel.DistributedDataParallel(model)
+        loss, _ = ddp(batches[rank])
+        loss.backward()
+        torch.cuda.synchronize()
+        res = {}
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                res[k] = float((p.grad - ref[k]).abs().max() / ref[k].abs().max().clamp(min=1e-12))
+        lt = torch.tensor([float(loss.detach())], device=dev)
+        dist.all_reduce(lt)
+        res["loss"] = abs(float(lt) / world - total) / max(abs(total), 1e-12)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_over_graphs_md17():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ddp, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert len(res) > 50
+        for k, v in res.items():
+            assert v < 2e-4, (rank, k, v)
