@@ -15,6 +15,7 @@ For every metric in {Cl(2,0), Cl(3,0), Cl(5,0), Cl(4,1)} it records
   egcl_<alg>.npz     EGCL fwd + all grads at N=12, E=40 (duplicate edges,
                      self loops, one isolated node), aggr in {sum, mean},
                      residual on/off, attr grads, fp32 and fp64 runs
+  egcl8_<alg>.npz    (`make_golden.py egcl8`, Cl(3,0) and Cl(4,1)) the same cases at 8 channels
 """
 import os
 import sys
@@ -148,9 +149,9 @@ def _load_f32_params(layer64, layer32):
     layer64.load_state_dict(sd, strict=True)
 
 
-def make_egcl(name, metric):
+def make_egcl(name, metric, C=4, kind="egcl"):
     out = {}
-    N, E, C, T = 12, 40, 4, 3
+    N, E, T = 12, 40, 3
     # inputs are drawn once in float32 and cast; layers are initialised once in float32 and the
     # float64 run loads the same parameters (round 1 drew them twice under different default
     # dtypes: the f32 and f64 fixtures then described different layers)
@@ -232,7 +233,7 @@ def make_egcl(name, metric):
         run("f64", torch.float64, layer64, tag, h0_32.double(),
             None if ea32 is None else ea32.double(), None if na32 is None else na32.double(), attr_grad)
         torch.set_default_dtype(torch.float32)
-    np.savez_compressed(os.path.join(HERE, f"egcl_{name}.npz"), **out)
+    np.savez_compressed(os.path.join(HERE, f"{kind}_{name}.npz"), **out)
 
 
 def make_state_dict_keys():
@@ -244,6 +245,13 @@ def make_state_dict_keys():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "egcl8":
+        # round 3: the same EGCL cases at 8 channels - the width the lane kernels serve ((row, channel)-per-lane kernels
+        # for Cl(3,0), parity-lane kernels for Cl(4,1)), so that the deterministic mode can be held to the fixture
+        for name in ("cl30", "cl41"):
+            make_egcl(name, ALGEBRAS[name], C=8, kind="egcl8")
+            print("8-channel EGCL vectors written for", name)
+        sys.exit(0)
     for name, metric in ALGEBRAS.items():
         make_tables(name, metric)
         make_algebra(name, metric)
