@@ -14,6 +14,8 @@ gradient's dot product with a seeded Gaussian direction (both runs) plus, for pa
   traj_hulls.npz    the 20-step Adam (lr 1e-3) loss trajectory of the hulls model (starting from
                     model_hulls.npz's parameters) over two alternating 4-graph batches (the "matching reference MSE" proxy: the real
                     dataset needs gudhi / DATAROOT).
+  stages_hulls.npz  (`make_model_golden.py stages`, round 3) embedding output and x behind every EGCL layer of the
+                    hulls model on model_hulls.npz's parameters and batch.
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
 loaded by file path so that the reference's `csmpn` namespace stays in front).
 """
@@ -185,7 +187,56 @@ def make_md17():
     print("md17 model: loss", out["f32/backprop_loss"], out["f64/backprop_loss"])
 
 
+def make_hulls_stages():
+    """Round 3: the intermediate tensors of the hulls model on model_hulls.npz's parameters and batch - the output of
+    embed_simplicial_complex (hulls_cssmpnn.py:96-125) and x behind each EGCL layer (hulls_cssmpnn.py:89-94) - so that
+    the embedding stage and the layer stack are pinned separately from the loss. Per tensor and per
+    run (float32, float64): its norm and its dot product with a seeded Gaussian direction; from the float64 run every
+    8th row whole (as float32)."""
+    ref = np.load(os.path.join(HERE, "model_hulls.npz"))
+    out = {}
+    torch.manual_seed(101)
+    model32 = HullsCliffordSharedSimplicialMPNN()
+    batch = hulls_batch(7)
+    sd = {k: v for k, v in model32.state_dict().items() if "algebra." not in k}
+    for k, v in sd.items():   # the same model as the loss fixture
+        assert np.array_equal(npy(v), ref["p/" + k]), k
+    for dt_name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dtype)
+        model = HullsCliffordSharedSimplicialMPNN()
+        full = model.state_dict()
+        for k, v in sd.items():
+            full[k] = v.to(dtype)
+        model.load_state_dict(full, strict=True)
+        got = {}
+        emb = model.embed_simplicial_complex
+
+        def traced(graph, _f=emb):
+            x = _f(graph)
+            got["embedding"] = x.detach().clone()
+            return x
+        model.embed_simplicial_complex = traced
+        hooks = [layer.register_forward_hook(lambda m, i, o, _k=k: got.__setitem__(f"layer{_k}", o.detach().clone()))
+                 for k, layer in enumerate(model.layers)]
+        loss, _ = model(namespace(batch, dtype), 0, "train")
+        for h in hooks:
+            h.remove()
+        assert abs(float(loss) - float(ref[f"{dt_name}/backprop_loss"])) <= 1e-6 * abs(float(loss))
+        for k, t in got.items():
+            out[f"{dt_name}/{k}/np"] = np.array([float(t.double().norm()), float((t.double() * direction_for(k, t.shape)).sum())])
+            if dt_name == "f64":
+                out[f"f64/{k}/rows"] = npy(t[::8]).astype(np.float32)
+            else:
+                out[f"f32/{k}/rows"] = npy(t[::8])
+        torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "stages_hulls.npz"), **out)
+    print("hulls stages:", {k: v.shape for k, v in out.items() if k.endswith("rows")})
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["stages"]:
+        make_hulls_stages()
+        sys.exit(0)
     which = sys.argv[1:] or ["md17", "hulls"]
     if "md17" in which:
         make_md17()

@@ -187,6 +187,48 @@ def test_model_fixture_gpu(pkg, kind):
 
 
 @pytest.mark.gpu
+def test_hulls_stages_gpu(pkg):
+    """The embedding stage (hulls_cssmpnn.py:96-125) and x behind every EGCL layer
+    (hulls_cssmpnn.py:89-94) against the reference's own intermediate tensors (stages_hulls.npz: every 8th row whole,
+    norm and a seeded projection of the full tensor; float32 run of the reference as the yardstick)."""
+    dev = torch.device("cuda:0")
+    g = np.load(os.path.join(GOLD, "model_hulls.npz"))
+    st = np.load(os.path.join(GOLD, "stages_hulls.npz"))
+    model = build(pkg, "hulls", g, dev)
+    batch = load_batch(pkg, g, device=dev)
+    got = {}
+    emb = model._embed
+    orig = emb.forward
+
+    def traced(b, blocks):
+        x = orig(b, blocks)
+        got["embedding"] = x.detach()
+        return x
+    emb.forward = traced
+    hooks = [layer.register_forward_hook(lambda m, i, o, _k=k: got.__setitem__(f"layer{_k}", o.detach()))
+             for k, layer in enumerate(model.layers)]
+    with torch.no_grad():
+        model(batch)
+    for h in hooks:
+        h.remove()
+    emb.forward = orig
+    assert sorted(got) == ["embedding", "layer0", "layer1", "layer2"]
+    for k, t in got.items():
+        t = t.double().cpu()
+        rows64, rows32 = st[f"f64/{k}/rows"].astype(np.float64), st[f"f32/{k}/rows"].astype(np.float64)
+        mine = t[::8].numpy()
+        scale = np.abs(rows64).max()
+        yard = np.abs(rows32 - rows64).max() / scale
+        err = np.abs(mine - rows64).max() / scale
+        assert err <= max(1e-5, 4 * yard), (k, err, yard)
+        n64, p64 = st[f"f64/{k}/np"]
+        n32, p32 = st[f"f32/{k}/np"]
+        nrm, prj = float(t.norm()), float((t * direction_for(k, t.shape)).sum())
+        assert abs(nrm - n64) <= max(1e-5, 4 * abs(n32 - n64) / n64) * n64, (k, nrm, n64)
+        assert abs(prj - p64) <= max(1e-5, 4 * abs(p32 - p64) / n64) * n64, (k, prj, p64)
+
+
+@pytest.mark.gpu
 def test_hulls_adam_trajectory_gpu(pkg):
     """20 Adam steps (lr 1e-3) over two alternating hull batches reproduce the reference's loss
     trajectory: the 'matching reference MSE on convex-hulls' proxy (north_star; the real dataset
