@@ -175,6 +175,7 @@ struct Plan {
     int var;              // VAR_WAVE / VAR_GROUP / VAR_GROUP_NM / VAR_GLOBAL
     int H;                // row halves per tile
     bool ps;              // parity-split kernels (cemlp_ps.hpp): 16-row tiles, 8 channels x 2 blade parities
+    bool det_general;     // deterministic mode on the general row-tile kernels: one row tile per workgroup, mirror slices
     void* workspace;      // the caller's workspace (the row-per-lane backward keeps its partial sums at its end)
     size_t workspace_bytes;
 };
@@ -359,7 +360,7 @@ int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool b
 // buf_g (edge forward scatter).
 int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads, int nblk,
               void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, bool use_saved, long rows,
-              Plan& plan) {
+              Plan& plan, bool deterministic = false) {
     if (nblk < 1 || nblk > CSMPN_MAX_BLOCKS) return fail(CSMPN_ERR_INVALID, "n_blocks=%d not in 1..%d", nblk, CSMPN_MAX_BLOCKS);
     const int D = 1 << n, G = n + 1, P = n_paths(id);
     memset(&plan, 0, sizeof(plan));
@@ -457,6 +458,14 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
             L = Ls; ch = cs; C.share_inz = 1;
         }
     }
+    // Deterministic mode on these kernels (n <= 3: Cl(2,0), Cl(3,0) widths outside the lane kernels - the md17 / NBA layers):
+    // ONE row tile per workgroup, so that every gradient word (LDS mirror or the workgroup's global copy) has one writing
+    // wave - the MT waves of a tile own disjoint channels - and the order of its sums is the tile order.
+    plan.det_general = false;
+    if (deterministic && n <= 3 && !ps && ch.var != VAR_GLOBAL) {
+        plan.det_general = true;
+        if (bwd) ch.rt = 1;
+    }
     C.off_in = L.off_in; C.off_p0 = L.off_p0; C.off_p1 = L.off_p1; C.off_z = L.off_z; C.off_g = L.off_g;
     C.off_red = L.off_red; C.off_idx = L.off_idx; C.tile_floats = L.total;
     const size_t tile_bytes = (size_t)L.total * 4;
@@ -481,6 +490,46 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     }
     plan.threads = (unsigned)(C.RT * MT * 64);
     return CSMPN_OK;
+}
+
+// Deterministic mode on the general kernels: every workgroup of a backward launch accumulates into its own zeroed copy of
+// the gradient tensors ([kDetGroups, slice] floats at the end of the workspace, reference layouts back to back);
+// det_reduce_kernel adds the copies in a fixed order.
+constexpr int kDetGroups = 128;
+int det_slice_floats_of(const csmpn_block_params* blocks, int nblk, int G, int P) {
+    int m = 0;
+    for (int k = 0; k < nblk; ++k)
+        m += rup(mirror_floats_of(blocks[k].in_features, blocks[k].out_features, G, P, blocks[k].lin_subspaces != 0), 4);
+    return m;
+}
+size_t det_slice_bytes(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n > 3 || nblk < 1) return 0;
+    // upper bound over the algebras with n generators: paths <= (n + 1)^3 (Cl(3,0): 20 of 64, Cl(2,0): 10 of 27)
+    const int G = n + 1, P = n == 3 ? 20 : (n == 2 ? 10 : (n + 1) * (n + 1) * (n + 1));
+    return (size_t)det_slice_floats_of(blocks, nblk, G, P) * sizeof(float) * kDetGroups + 256;
+}
+struct DetMap {
+    int n;
+    int total;
+    struct { float* dst; int off; int count; } t[40];
+};
+// grads += sum over the workgroups' copies, fixed order: one thread per word (consecutive threads read consecutive
+// words of a copy), eight copies in flight
+__global__ void __launch_bounds__(256) det_reduce_kernel(const DetMap M, const float* slices, int nslices) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= M.total) return;
+    float s = 0.f;
+    int w = 0;
+    for (; w + 8 <= nslices; w += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = slices[(size_t)(w + i) * M.total + e];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; w < nslices; ++w) s += slices[(size_t)w * M.total + e];
+    for (int i = 0; i < M.n; ++i)
+        if (e >= M.t[i].off && e < M.t[i].off + M.t[i].count) { M.t[i].dst[e - M.t[i].off] += s; return; }
 }
 
 int run_pack(const Plan& plan, hipStream_t st) {
@@ -736,11 +785,35 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (handled) return CSMPN_OK;
         }
     }
-    if (io.row_store)
+    if (io.row_store && !plan.det_general)
         return fail(CSMPN_ERR_UNSUPPORTED,
-                    "CSMPN_FLAG_DETERMINISTIC needs the lane kernels of Cl(3,0) (8 or 16 channels) or the wide parity-lane "
-                    "kernels (Cl(5,0) / Cl(4,1), 16 / 24 / 28 / 32 channels), two blocks with saved block inputs: the other "
-                    "kernel families sum parameter gradients with float atomics");
+                    "CSMPN_FLAG_DETERMINISTIC: this shape is served neither by the lane kernels (Cl(3,0) 8 / 16 channels, "
+                    "Cl(5,0) / Cl(4,1) 8 / 16 / 24 / 28 / 32 channels; two blocks with saved block inputs) nor by the deterministic "
+                    "form of the general kernels (n <= 3, tiles and gradient mirror resident in LDS)");
+    size_t det_bytes = 0;
+    float* det_slices = nullptr;
+    DetMap det_map;
+    int det_total = 0;
+    if (io.row_store && bwd) {   // per-workgroup copies of the gradient tensors at the end of the workspace
+        const int G = (id == ALG_N2) ? 3 : 4, P = n_paths(id);   // det_general: n <= 3
+        det_map.n = 0;
+        for (int k = 0; k < plan.C.nblk; ++k) {
+            const DevBlock& B = plan.C.b[k];
+            auto add = [&](float* dst, int count) {
+                if (dst) { det_map.t[det_map.n].dst = dst; det_map.t[det_map.n].off = det_total; det_map.t[det_map.n].count = count; ++det_map.n; }
+                det_total += count;
+            };
+            add(B.gW1, (B.w1_sub ? G : 1) * B.O * B.I); add(B.gWR, G * B.O * B.O); add(B.gWL, G * B.O * B.O);
+            add(B.has_b1 ? B.gb1 : nullptr, B.O); add(B.gsa, B.O * G); add(B.gsb, B.O * G); add(B.gw, B.O * P);
+            add(B.gan, B.O * G); add(B.gbL, B.O); add(B.gla, B.O);
+            det_total = rup(det_total, 4);
+        }
+        det_map.total = det_total;
+        det_bytes = (size_t)det_total * sizeof(float) * kDetGroups + 256;
+        if (!plan.workspace || plan.workspace_bytes < det_bytes)
+            return fail(CSMPN_ERR_INVALID, "workspace too small for the deterministic backward: %zu < %zu", plan.workspace_bytes, det_bytes);
+        det_slices = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - det_bytes) & ~(size_t)255));
+    }
     // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
     if (need_pack) {
         const int rcp = run_pack(plan, st);
@@ -764,13 +837,36 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     }
     long grid = (ntiles + Cd.RT - 1) / Cd.RT;
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
+    if (det_bytes && grid > kDetGroups) grid = kDetGroups;
     static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
     if (debug)
         fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d share=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
                 mode, (int)bwd, plan.var, (int)plan.ps, Cd.share_inz, plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
                 Cd.tile_floats, Cd.mirror_floats, io.rows);
+    if (det_bytes) {
+        // the kernels' accumulators = copy 0 of the zeroed region; workgroup b adds b * det_slice_floats
+        HIP_TRY(hipMemsetAsync(det_slices, 0, (size_t)grid * det_total * sizeof(float), st));
+        Cd.det_slice_floats = det_total;
+        for (int i = 0, k = 0, j = 0; k < Cd.nblk; ++k) {
+            DevBlock& B = Cd.b[k];
+            float** ptrs[10] = {&B.gW1, &B.gWR, &B.gWL, &B.gb1, &B.gsa, &B.gsb, &B.gw, &B.gan, &B.gbL, &B.gla};
+            const int G = (id == ALG_N2) ? 3 : 4, P = n_paths(id);
+            const int counts[10] = {(B.w1_sub ? G : 1) * B.O * B.I, G * B.O * B.O, G * B.O * B.O, B.O, B.O * G, B.O * G, B.O * P, B.O * G, B.O, B.O};
+            for (int q = 0; q < 10; ++q) {
+                if (q == 3 && !B.has_b1) { j += counts[q]; continue; }
+                *ptrs[q] = det_slices + j;
+                j += counts[q];
+            }
+            j = rup(j, 4);
+            (void)i;
+        }
+    }
     if (plan.ps) HIP_TRY(launch_cemlp_ps(id, mode, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
     else HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
+    if (det_bytes) {
+        hipLaunchKernelGGL(det_reduce_kernel, dim3((det_total + 255) / 256), dim3(256), 0, st, det_map, (const float*)det_slices, (int)grid);
+        HIP_TRY(hipGetLastError());
+    }
     return CSMPN_OK;
 }
 
@@ -982,7 +1078,9 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
         const size_t s2 = (size_t)kGlobalTileGrid * grt * Lf.total * 4;
         scratch = s2 > scratch ? s2 : scratch;
     }
-    return ((bytes + scratch + 15) & ~(size_t)15) + rl_partial_bytes(n, blocks, n_blocks) + plw_table_bytes(n, blocks, n_blocks) + 16;
+    const size_t tail = rl_partial_bytes(n, blocks, n_blocks) + plw_table_bytes(n, blocks, n_blocks);
+    const size_t det = det_slice_bytes(n, blocks, n_blocks);   // never together with a lane-kernel region: the larger one
+    return ((bytes + scratch + 15) & ~(size_t)15) + (tail > det ? tail : det) + 16 + 256;
 }
 
 int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* x,
@@ -990,7 +1088,8 @@ int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* bl
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
-    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, rows, plan);
+    int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, rows, plan,
+                       (flags & CSMPN_FLAG_DETERMINISTIC) != 0);
     if (rc) return rc;
     const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     RowIO io;
@@ -1007,17 +1106,18 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     Plan plan;
-    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, rows, plan);
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, rows, plan,
+                       (flags & CSMPN_FLAG_DETERMINISTIC) != 0);
     if (rc) return rc;
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
-    (void)flags;
     const bool need_pack = true;
     RowIO io;
     memset(&io, 0, sizeof(io));
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
+    io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // standalone CEMLP: no row table, atomic-free parameter sums only
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
 }
 
@@ -1072,7 +1172,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     const int D = 1 << n;
     Plan plan;
     int rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false,
-                       blocks[n_blocks - 1].out_features * D, false, E, plan);
+                       blocks[n_blocks - 1].out_features * D, false, E, plan, (flags & CSMPN_FLAG_DETERMINISTIC) != 0);
     if (rc) return rc;
     const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     RowIO io;
@@ -1098,7 +1198,8 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     if (channels + attr_channels != blocks[0].in_features)
         return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
     Plan plan;
-    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, E, plan);
+    int rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, E, plan,
+                       (flags & CSMPN_FLAG_DETERMINISTIC) != 0);
     if (rc) return rc;
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
@@ -1145,7 +1246,8 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
                      residual, N, io);
     if (rc) return rc;
     Plan plan;
-    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, N, plan))) return rc;
+    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, N, plan,
+                        (flags & CSMPN_FLAG_DETERMINISTIC) != 0))) return rc;
     const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     io.y = out; io.resid = residual ? h : nullptr; io.save = save_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // node stage: no row table, only atomic-free kernels qualify
@@ -1165,10 +1267,10 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
                      residual, N, io);
     if (rc) return rc;
     Plan plan;
-    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, N, plan))) return rc;
+    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, N, plan,
+                        (flags & CSMPN_FLAG_DETERMINISTIC) != 0))) return rc;
     // fragments packed by the forward are only valid for the forward's own layout choice (a forward
     // with LDS-staged raw weights packs nothing): the backward packs for itself; no-op for VAR_WAVE
-    (void)flags;
     const bool need_pack = true;
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;

@@ -77,6 +77,8 @@ struct DevCemlp {
                          // again in front of the MVLinear weight gradient (one more row tile per CU
                          // where LDS, not registers, limits the resident waves)
     float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
+    int det_slice_floats;  // > 0: deterministic mode of the general kernels - the g* pointers are slice 0 of a per-workgroup region
+    int pad_det_;
     DevBlock b[4];
 };
 
@@ -756,7 +758,9 @@ template <class ALG, int H, int VAR>
 CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, const FwdState<ALG>& S,
                               const f4 (&gout)[ALG::D], const float* xin, const float* zbuf, float* gbuf,
                               float* red, float* mirror, const float* wstore, int MT, int mt,
-                              const Geo<ALG, H>& ge, f4 (&gy)[ALG::D], bool defer_w1 = false) {
+                              const Geo<ALG, H>& ge, f4 (&gy)[ALG::D], bool defer_w1 = false, size_t goff = 0) {
+    // goff: deterministic mode of the general kernels - float offset of this WORKGROUP's private copy of the gradient
+    // accumulators (the host points g* at slice 0 of a zeroed per-workgroup region); 0 otherwise
     using GE = Geo<ALG, H>;
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P, NW = GE::NW;
     const int c = NW * mt + ge.cn;
@@ -777,8 +781,8 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
         d_b1 = mir + mo.b1; d_sa = mir + mo.sa; d_sb = mir + mo.sb; d_w = mir + mo.w; d_an = mir + mo.an;
         d_bL = mir + mo.bL; d_la = mir + mo.la; d_W1 = mir + mo.W1; d_WR = mir + mo.WR; d_WL = mir + mo.WL;
     } else {
-        d_b1 = B.gb1; d_sa = B.gsa; d_sb = B.gsb; d_w = B.gw; d_an = B.gan;
-        d_bL = B.gbL; d_la = B.gla; d_W1 = B.gW1; d_WR = B.gWR; d_WL = B.gWL;
+        d_b1 = B.gb1 + goff; d_sa = B.gsa + goff; d_sb = B.gsb + goff; d_w = B.gw + goff; d_an = B.gan + goff;
+        d_bL = B.gbL + goff; d_la = B.gla + goff; d_W1 = B.gW1 + goff; d_WR = B.gWR + goff; d_WL = B.gWL + goff;
     }
     // per-lane partial sums (over the lane's 4 rows) of the small-parameter gradients; all
     // lanes of a channel add them to the accumulators in one predicated region at the end
@@ -942,17 +946,17 @@ CSMPN_DEV void block_backward(const DevBlock& B, const LaneParams<ALG>& lp, cons
 // the MVLinear weight gradient of block_backward, for callers that deferred it (defer_w1)
 template <class ALG, int H, int VAR>
 CSMPN_DEV void block_w1_grad(const DevBlock& B, const f4 (&gy)[ALG::D], const float* xin, float* mirror, int mt,
-                             const Geo<ALG, H>& ge) {
+                             const Geo<ALG, H>& ge, size_t goff = 0) {
     constexpr int G = ALG::G, NW = Geo<ALG, H>::NW;
     constexpr bool in_lds = kVarMirror<VAR>;
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, ALG::P, B.w1_sub != 0);
-    float* d_W1 = in_lds ? mirror + B.lds_goff + mo.W1 : B.gW1;
+    float* d_W1 = in_lds ? mirror + B.lds_goff + mo.W1 : B.gW1 + goff;
     if (NW * mt < B.O) weight_grad<ALG, H, in_lds>(gy, xin, B.CPi, B.I, B.O, B.NTi, mt, ge, d_W1, B.w1_sub != 0);
 }
 
 // flush one block's LDS gradient mirror into the global reference-layout accumulators
 template <class ALG>
-__device__ void flush_mirror(const DevBlock& B, const float* mirror, int tid, int nthreads) {
+__device__ void flush_mirror(const DevBlock& B, const float* mirror, int tid, int nthreads, size_t goff = 0) {
     constexpr int G = ALG::G, P = ALG::P;
     const MirrorOff mo = mirror_offsets(B.I, B.O, G, P, B.w1_sub != 0);
     const float* mir = mirror + B.lds_goff;
@@ -962,25 +966,25 @@ __device__ void flush_mirror(const DevBlock& B, const float* mirror, int tid, in
         // mirror [g][o][i] -> reference [o][i][g]
         const int g = e / (O * I), rem = e % (O * I);
         const float v = mir[mo.W1 + e];
-        if (v != 0.f) atomicAdd(B.gW1 + (B.w1_sub ? rem * G + g : rem), v);
+        if (v != 0.f) atomicAdd(B.gW1 + goff + (B.w1_sub ? rem * G + g : rem), v);
     }
     for (int e = tid; e < G * O * O; e += nthreads) {
         const int g = e / (O * O), rem = e % (O * O);
         const float vr = mir[mo.WR + e], vl = mir[mo.WL + e];
-        if (vr != 0.f) atomicAdd(B.gWR + rem * G + g, vr);
-        if (vl != 0.f) atomicAdd(B.gWL + rem * G + g, vl);
+        if (vr != 0.f) atomicAdd(B.gWR + goff + rem * G + g, vr);
+        if (vl != 0.f) atomicAdd(B.gWL + goff + rem * G + g, vl);
     }
     for (int e = tid; e < O; e += nthreads) {
-        if (B.has_b1) atomicAdd(B.gb1 + e, mir[mo.b1 + e]);
-        atomicAdd(B.gbL + e, mir[mo.bL + e]);
-        atomicAdd(B.gla + e, mir[mo.la + e]);
+        if (B.has_b1) atomicAdd(B.gb1 + goff + e, mir[mo.b1 + e]);
+        atomicAdd(B.gbL + goff + e, mir[mo.bL + e]);
+        atomicAdd(B.gla + goff + e, mir[mo.la + e]);
     }
     for (int e = tid; e < O * G; e += nthreads) {
-        atomicAdd(B.gsa + e, mir[mo.sa + e]);
-        atomicAdd(B.gsb + e, mir[mo.sb + e]);
-        atomicAdd(B.gan + e, mir[mo.an + e]);
+        atomicAdd(B.gsa + goff + e, mir[mo.sa + e]);
+        atomicAdd(B.gsb + goff + e, mir[mo.sb + e]);
+        atomicAdd(B.gan + goff + e, mir[mo.an + e]);
     }
-    for (int e = tid; e < O * P; e += nthreads) atomicAdd(B.gw + e, mir[mo.w + e]);
+    for (int e = tid; e < O * P; e += nthreads) atomicAdd(B.gw + goff + e, mir[mo.w + e]);
 }
 
 }  // namespace csmpn

@@ -182,6 +182,15 @@ CSMPN_DEV void store_dense(const f4 (&t)[ALG::D], float* stage, int nch, int ch,
     }
 }
 
+// rows of a dense staged tile -> rows row0 .. of a [rows, rowlen] table (deterministic mode: the edge rows are not
+// scattered; a segmented reduction sums them afterwards in a fixed order)
+template <class ALG, int H>
+__device__ void store_rows_dense(const float* stage, int rowlen, long row0, long rows, float* table, int tid, int nthreads) {
+    constexpr int R = 16 * H;
+    const long nr = rows - row0 < R ? rows - row0 : R;
+    for (long e = tid; e < nr * rowlen; e += nthreads) table[row0 * rowlen + e] = stage[e];
+}
+
 // rows of a dense staged tile -> atomic adds into table rows selected by lidx (LDS copy of
 // the tile's row indices, -1 = masked row), sign * value.
 // SEGMENTED (single-wave tiles, rows sorted by index): equal consecutive targets are summed first.
@@ -331,6 +340,7 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rt = wave / MT, mt = wave - rt * MT;
     const int tid_rt = mt * 64 + lane, nthr_rt = MT * 64;
+    const size_t det_goff = (size_t)blockIdx.x * (size_t)C.det_slice_floats;   // deterministic mode: this workgroup's accumulator copy
     const GE ge(lane);
     constexpr bool WLDS = VAR == VAR_WAVE;
     float* mirror = smem;
@@ -450,7 +460,8 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                 tile_sync<VAR>();
                 store_dense<ALG, H>(out, buf_g, O, c, ge);
                 tile_sync<VAR>();
-                if constexpr (!MULTI) scatter_tile<ALG, H>(buf_g, O * D, tidx, nullptr, io.agg, lane);
+                if (io.row_store) store_rows_dense<ALG, H>(buf_g, O * D, row0, io.rows, io.agg, tid_rt, nthr_rt);
+                else if constexpr (!MULTI) scatter_tile<ALG, H>(buf_g, O * D, tidx, nullptr, io.agg, lane);
                 else scatter_rows<ALG, H, false>(buf_g, O * D, tidx, io.agg, 1.0f, tid_rt, nthr_rt);
                 tile_sync<VAR>();
                 ge.stamp(18);
@@ -537,13 +548,13 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     const bool share = H == 1 && C.share_inz != 0;
                     block_forward<ALG, H, VAR, BWD>(B, lp, in, buf_z, red, wstore, MT, mt, ge, S, unused, share);
                     if constexpr (PARK) { tile_sync<VAR>(); unpark<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
-                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy, share);
+                    block_backward<ALG, H, VAR>(B, lp, S, gout, in, buf_z, buf_g, red, mirror, wstore, MT, mt, ge, gy, share, det_goff);
                     if (share) {
                         // z lived in the input buffer: bring the block's input tile back for the MVLinear weight gradient
                         if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
                         else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
                         tile_sync<VAR>();
-                        block_w1_grad<ALG, H, VAR>(B, gy, buf_in, mirror, mt, ge);
+                        block_w1_grad<ALG, H, VAR>(B, gy, buf_in, mirror, mt, ge, det_goff);
                         tile_sync<VAR>();
                     }
                 }
@@ -607,7 +618,9 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     ge.stamp(17);
                     if constexpr (MODE == MODE_EDGE) {
                         tile_sync<VAR>();
-                        if (io.gx[0]) {
+                        if (io.gx[0] && io.row_store) {
+                            store_rows_dense<ALG, H>(stage, Cs0 * D, row0, io.rows, io.gx[0], tid_rt, nthr_rt);
+                        } else if (io.gx[0]) {
                             if constexpr (!MULTI) {
                                 scatter_tile<ALG, H>(stage, Cs0 * D, tidx, tidx + R, io.gx[0], lane);
                             } else {
@@ -625,7 +638,10 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
 
     if constexpr (BWD && in_lds) {
         __syncthreads();
-        for (int k = 0; k < C.nblk; ++k) flush_mirror<ALG>(C.b[k], mirror, threadIdx.x, blockDim.x);
+        // deterministic mode: this workgroup's private copy of the accumulators (one row tile per workgroup: every word
+        // has one writing wave, in tile order); det_reduce_kernel adds the copies in a fixed order
+        for (int k = 0; k < C.nblk; ++k)
+            flush_mirror<ALG>(C.b[k], mirror, threadIdx.x, blockDim.x, (size_t)blockIdx.x * (size_t)C.det_slice_floats);
     }
 #ifdef CSMPN_STAMPS
     ge.stamp(19);

@@ -336,6 +336,9 @@ __global__ void __launch_bounds__(256) rl_reduce_kernel(const DevCemlp C_arg, co
 // helpers put four 16-byte reads in flight and let the caller decide where to wait.
 CSMPN_DEV unsigned rl_lds_addr(const float* p) { return (unsigned)(unsigned long long)p; }   // LDS byte address
 template <int O0, int O1, int O2, int O3>
+// (No "memory" clobber: the only data read this way is the weight store, written once in front of the workgroup barrier
+// that opens the tile loop. The registers in flight between this statement and rl_lds_wait are audited at build time:
+// `make check-asm` / tools/check_asm_waits.py fails the build if a compiler instruction touches them.)
 CSMPN_DEV void rl_lds_read4(unsigned a, f4 (&w)[4]) {   // byte offsets from a; read-only data (the weight store)
     asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"
                  "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"

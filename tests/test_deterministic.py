@@ -94,7 +94,11 @@ def _run_layer(pkg, C, seed, N=2000, E=20000, metric=(1.0, 1.0, 1.0)):
                                           # the wide parity-lane kernels: the convex-hulls width, and Cl(4,1)
                                           (28, (1.0,) * 5, 400, 4000), (16, (1.0, 1.0, 1.0, 1.0, -1.0), 300, 3000),
                                           # 8 channels of D = 32: routed to the one-group wide kernels in this mode
-                                          (8, (1.0, 1.0, 1.0, 1.0, -1.0), 500, 5000)])
+                                          (8, (1.0, 1.0, 1.0, 1.0, -1.0), 500, 5000),
+                                          # round 3: the general row-tile kernels in their deterministic form (one row tile per
+                                          # workgroup, mirror slices + fixed-order reduction): the md17 width (Cl(3,0), 32 channels),
+                                          # the NBA width (Cl(2,0), 40 channels), an odd narrow width
+                                          (32, (1.0, 1.0, 1.0), 600, 6000), (40, (1.0, 1.0), 400, 4000), (5, (1.0, 1.0, 1.0), 700, 5000)])
 def test_bit_reproducible(pkg, det, C, metric, N, E):
     once = _run_layer(pkg, C, seed=11, N=N, E=E, metric=metric)
     a = once()
@@ -104,10 +108,10 @@ def test_bit_reproducible(pkg, det, C, metric, N, E):
             assert torch.equal(x, y), f"tensor {i} differs between two runs in deterministic mode"
 
 
-@pytest.mark.parametrize("C", [8, 16])
-def test_matches_atomic_mode(pkg, C):
+@pytest.mark.parametrize("C,metric", [(8, (1.0, 1.0, 1.0)), (16, (1.0, 1.0, 1.0)), (32, (1.0, 1.0, 1.0)), (40, (1.0, 1.0))])
+def test_matches_atomic_mode(pkg, C, metric):
     from csmpn_hip import ops
-    once = _run_layer(pkg, C, seed=12)
+    once = _run_layer(pkg, C, seed=12, metric=metric)
     ops.set_deterministic(False)
     try:
         a = once()
@@ -121,7 +125,8 @@ def test_matches_atomic_mode(pkg, C):
 
 
 @pytest.mark.parametrize("metric,C,aggr,N,E", [((1.0, 1.0, 1.0), 8, "mean", 300, 2999), ((1.0, 1.0, 1.0), 16, "sum", 300, 2999),
-                                               ((1.0,) * 5, 28, "mean", 120, 1001)])
+                                               ((1.0,) * 5, 28, "mean", 120, 1001),
+                                               ((1.0, 1.0, 1.0), 32, "sum", 200, 1501), ((1.0, 1.0), 40, "mean", 150, 999)])
 def test_parity_vs_oracle(pkg, det, metric, C, aggr, N, E):
     _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=5)
 
