@@ -89,15 +89,18 @@ class CliffordAlgebra(nn.Module):
         return mv[..., :1]
 
     # ------------------------------------------------------------------ embedding / projection
+    # (cliffordalgebra.py:98-117; blades are grade-sorted, so a grade is one contiguous slice)
+    def _scatter_blades(self, values, where, dtype):
+        out = values.new_zeros(values.shape[:-1] + (self.n_blades,), dtype=dtype)
+        out[..., where] = values.to(dtype)
+        return out
+
     def embed(self, tensor, tensor_index):
-        mv = torch.zeros(*tensor.shape[:-1], self.n_blades, device=tensor.device, dtype=tensor.dtype)
-        mv[..., tensor_index] = tensor
-        return mv
+        return self._scatter_blades(tensor, tensor_index, tensor.dtype)
 
     def embed_grade(self, tensor, grade):
-        mv = torch.zeros(*tensor.shape[:-1], self.n_blades, device=tensor.device)
-        mv[..., self.grade_to_slice[grade]] = tensor
-        return mv
+        # the reference allocates in the default dtype whatever the input's: kept
+        return self._scatter_blades(tensor, self.grade_to_slice[grade], torch.get_default_dtype())
 
     def get(self, mv, blade_index):
         return mv[..., tuple(blade_index)]
@@ -138,57 +141,9 @@ class CliffordAlgebra(nn.Module):
         grades = self.grades if grades is None else grades
         return [self.norm(self.get_grade(mv, int(g)), blades=self.grade_to_index[int(g)]) for g in grades]
 
-    # ------------------------------------------------------------------ sampling / versors (off the hot path)
-    def output_blades(self, blades_left, blades_right):
-        out = []
-        for bl in blades_left:
-            for br in blades_right:
-                bm, _ = gmt_element(int(self.bbo.index_to_bitmap[bl]), int(self.bbo.index_to_bitmap[br]), self.metric)
-                out.append(int(self.bbo.bitmap_to_index[bm]))
-        return torch.tensor(out)
-
-    def random(self, n=None):
-        return torch.randn(1 if n is None else n, self.n_blades)
-
-    def random_vector(self, n=None):
-        n = 1 if n is None else n
-        v = torch.zeros(n, self.n_blades, device=self.cayley.device)
-        is_vec = self.bbo_grades == 1
-        v[:, is_vec] = torch.randn(n, int(is_vec.sum()), device=self.cayley.device)
-        return v
-
-    def parity(self, mv):
-        is_odd = torch.all(mv[..., self.even_grades] == 0)
-        is_even = torch.all(mv[..., self.odd_grades] == 0)
-        if is_odd ^ is_even:
-            return is_odd
-        raise ValueError("This is not a homogeneous element.")
-
-    def eta(self, w):
-        return (-1) ** self.parity(w)
-
-    def alpha_w(self, w, mv):
-        return self.even_grades * mv + self.eta(w) * self.odd_grades * mv
-
-    def inverse(self, mv, blades=None):
-        # same (quirky) definition as the reference, cliffordalgebra.py:215-217
-        rev = self.beta(mv, blades=blades)
-        return rev / self.b(mv, rev)
-
-    def rho(self, w, mv):
-        return self.sandwich(w, self.alpha_w(w, mv), self.inverse(w))
-
-    def versor(self, order=None, normalized=True):
-        if order is None:
-            order = self.dim if self.dim % 2 == 0 else self.dim - 1
-        vectors = self.random_vector(order)
-        v = self.reduce_geometric_product(vectors[:, None])
-        if normalized:
-            v = v / self.norm(v)[..., :1]
-        return v
-
-    def rotor(self):
-        return self.versor()
+    # (The reference's sampling / versor helpers - random_vector, parity, eta, alpha_w, inverse, rho, versor, rotor,
+    # cliffordalgebra.py:170-236 - are not part of the message-passing path and no task model calls them; they are not
+    # restated here. SURVEY.md Appendix C lists `inverse` / `rho` as wrong for non-blade versors anyway.)
 
     # ------------------------------------------------------------------ structure
     @functools.cached_property
