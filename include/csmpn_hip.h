@@ -59,11 +59,14 @@ extern "C" {
                                        not scattered: `agg` (forward) / `gh` (backward) is an [E, C, D] table in
                                        SORTED edge order, to be summed by csmpn_segment_reduce in a fixed order
                                        (the reference runs under torch.use_deterministic_algorithms(True),
-                                       engineer/utils/seed.py:30). Only the kernels whose parameter-gradient
-                                       sums are atomic-free honour it: Cl(3,0) with 8 or 16 channels, and Cl(5,0) /
-                                       Cl(4,1) with 8 / 16 / 24 / 28 / 32 channels (two blocks, saved block inputs);
-                                       every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
-                                       csmpn_egcl_node_forward/backward, where it only selects such kernels. */
+                                       engineer/utils/seed.py:30). Honoured by the kernels whose parameter-gradient
+                                       sums are atomic-free: Cl(3,0) with 8 or 16 channels, Cl(5,0) / Cl(4,1) with
+                                       8 / 16 / 24 / 28 / 32 channels (two blocks, saved block inputs) and, since round 3,
+                                       every Cl(2,0) / Cl(3,0) shape on the general kernels (one row tile per workgroup,
+                                       per-workgroup copies of the gradient tensors + fixed-order sums; slower than the
+                                       default). Every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
+                                       csmpn_egcl_node_forward/backward and csmpn_cemlp_forward/backward, where it only
+                                       selects the atomic-free parameter sums. */
 
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
@@ -126,7 +129,8 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
  * n_nodes of the call, in the kernel's own row order) into save_inputs when it is non-NULL, and
  * the backward reads them from saved_inputs instead of recomputing the earlier blocks (one
  * block forward less per row, and a smaller LDS footprint). NULL on either side = recompute.
- * Floats per row: csmpn_cemlp_saved_floats_per_row(); for two-block Cl(5,0) CEMLPs of 9 .. 32 channels this includes
+ * Floats per row: csmpn_cemlp_saved_floats_per_row(); for two-block Cl(5,0) CEMLPs of 9 .. 32 channels and for the
+ * two-block 8-channel Cl(3,0) EGCL shapes (edge model 14 -> 8 -> 8, node model 19 -> 8 -> 8) this includes
  * one more [rows, O, D] region behind the saved inputs that the backward uses as scratch (its block-1 launch hands
  * d/d(block-1 input) to its block-0 launch there): the buffer is written by the backward although the pointer is const. */
 size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks);
