@@ -68,9 +68,28 @@ class SimplexEmbedding(nn.Module):
         dev = batch.x_ind.device
         out = torch.zeros(batch.x_ind.shape[0], self.hidden_features, D, device=dev)
         fused = dev.type == "cuda" and not any(t.requires_grad for t, _ in vertex_blocks)
+        # Fused embedding (round 3, csmpn_embed_cemlp_*): for d >= 1 the vertex features are gathered in every vertex order
+        # inside the CEMLP kernel and the sum over the orders is taken there - neither the [n_d (d+1)!, (d+1) K, D] input
+        # rows nor the per-order outputs exist in memory. Served for one feature block on the wide parity-lane shapes (the
+        # convex-hulls model); everything else composes simplex_rows + CEMLP + reshape-sum as before.
+        emb_feat = None
+        import os
+        if fused and len(vertex_blocks) == 1 and os.environ.get("CSMPN_NO_FUSED_EMBED", "0") in ("", "0"):
+            from csmpn_hip import ops
+            t0, g0 = vertex_blocks[0]
+            if all(ops.embed_cemlp_supported(self.cl_feature_embedding[d].binding(), d + 1, t0.shape[1])
+                   for d in range(1, self.max_dim + 1)):
+                emb_feat = self.algebra.embed_grade(t0, g0).contiguous()      # [S, K, D]: no vertex-order blow-up
+                if "verts_i32" not in plan:
+                    plan["verts_i32"] = [v.to(torch.int32).contiguous() for v in plan["verts"]]
         for d in range(self.max_dim + 1):
             rows, pv, nperm = plan["rows"][d], plan["verts"][d], plan["nperm"][d]
             if rows.shape[0] == 0:
+                continue
+            if emb_feat is not None and d >= 1:
+                mod = self.cl_feature_embedding[d]
+                e = ops.embed_cemlp_apply(emb_feat, plan["verts_i32"][d], nperm, mod.binding(), mod.flat_params())
+                out = out.index_copy(0, rows, e)
                 continue
             if fused:
                 from csmpn_hip import ops

@@ -239,6 +239,68 @@ def cemlp_apply(x, binding: CemlpBinding, params):
     return _CemlpFn.apply(x, binding, *params)
 
 
+_EMBED_LAUNCHES = 0
+
+
+def embed_launches() -> int:
+    """Forward launches of the fused embedding entry point so far (tests assert that the HIP path ran)."""
+    return _EMBED_LAUNCHES
+
+
+class _EmbedCemlpFn(torch.autograd.Function):
+    """Fused simplex embedding (csmpn_embed_cemlp_*; hulls_cssmpnn.py:96-125): vertex features gathered in every vertex
+    order -> CEMLP -> sum over the orders, without the [n_simplices * (d+1)!, ., D] input / output rows in memory.
+    vertex_feat [S, K, D] (data: no gradient), verts [n_simplices * n_orders, d+1] int32."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, vertex_feat, verts, n_orders, binding: CemlpBinding, *params):
+        _require_device(vertex_feat, "embedding vertex features")
+        binding.bind(params)
+        rows = int(verts.shape[0])
+        out = torch.empty(rows // n_orders, binding.out_features, binding.D, dtype=torch.float32, device=vertex_feat.device)
+        ws = binding.workspace(vertex_feat.device)
+        need_grad = any(ctx.needs_input_grad[4:])
+        saved = binding.new_saved(rows, vertex_feat.device) if need_grad else None
+        check(native.lib().csmpn_embed_cemlp_forward(
+            binding.metric_arr, binding.n, binding.params, binding.nblk, vertex_feat.data_ptr(), int(vertex_feat.shape[1]),
+            verts.data_ptr(), int(verts.shape[1]), int(n_orders), rows, out.data_ptr(), _ptr(saved), ws.data_ptr(), ws.numel(),
+            0, _stream(vertex_feat.device)))
+        global _EMBED_LAUNCHES
+        _EMBED_LAUNCHES += 1
+        ctx.binding, ctx.param_refs, ctx.ws, ctx.saved, ctx.n_orders = binding, params, ws, saved, int(n_orders)
+        ctx.save_for_backward(vertex_feat, verts, *[p for p in params if p is not None])
+        ctx.mask = [p is not None for p in params]
+        return out
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, gout):
+        binding = ctx.binding
+        vertex_feat, verts, *present = ctx.saved_tensors
+        it = iter(present)
+        params = [next(it) if m else None for m in ctx.mask]
+        gout = gout.contiguous()
+        binding.bind(params)
+        fused = ctx.param_refs if _fusable(ctx.param_refs, vertex_feat.device) else None
+        _flat, views = binding.new_grads(params, vertex_feat.device, fused_into=fused)
+        check(native.lib().csmpn_embed_cemlp_backward(
+            binding.metric_arr, binding.n, binding.params, binding.grads, binding.nblk, vertex_feat.data_ptr(),
+            int(vertex_feat.shape[1]), verts.data_ptr(), int(verts.shape[1]), ctx.n_orders, int(verts.shape[0]),
+            gout.data_ptr(), _ptr(ctx.saved), ctx.ws.data_ptr(), ctx.ws.numel(), 0, _stream(vertex_feat.device)))
+        return (None, None, None, None, *views)
+
+
+def embed_cemlp_supported(binding: CemlpBinding, verts_per_row: int, channels_per_vertex: int) -> bool:
+    """Shapes the fused embedding serves: Cl(5,0) / Cl(4,1), 16 / 24 / 28 / 32 output channels, <= 8 input channels."""
+    return (binding.n == 5 and binding.nblk in (1, 2) and binding.out_features in (16, 24, 28, 32)
+            and verts_per_row * channels_per_vertex == binding.in_features <= 8)
+
+
+def embed_cemlp_apply(vertex_feat, verts_i32, n_orders, binding: CemlpBinding, params):
+    return _EmbedCemlpFn.apply(vertex_feat, verts_i32, n_orders, binding, *params)
+
+
 # --------------------------------------------------------------------------------- CSR
 
 

@@ -1121,6 +1121,59 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
 }
 
+// Fused simplex embedding (include/csmpn_hip.h): MODE_PLAIN of the wide parity-lane kernels with the embed descriptor
+static int embed_io(const AlgId id, const csmpn_block_params* blocks, const float* vertex_feat, int32_t kpv, const int32_t* verts,
+                    int32_t nv, int32_t n_orders, int64_t n_rows, RowIO& io) {
+    if (id != ALG_N5 && id != ALG_N5M) return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: Cl(5,0) / Cl(4,1) only");
+    if (n_orders != 1 && n_orders != 2 && n_orders != 6) return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: 1, 2 or 6 vertex orders");
+    if (!vertex_feat || !verts || kpv < 1 || nv < 1 || nv * kpv != blocks[0].in_features || nv * kpv > 8)
+        return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: verts_per_row * channels_per_vertex must equal in_features (<= 8)");
+    if (n_rows % n_orders) return fail(CSMPN_ERR_INVALID, "fused embedding: n_rows %ld is not a multiple of n_orders %d", (long)n_rows, n_orders);
+    memset(&io, 0, sizeof(io));
+    io.rows = n_rows; io.nseg = 1;
+    io.seg[0].a = vertex_feat; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
+    io.emb_verts = verts; io.emb_nperm = n_orders; io.emb_nv = nv; io.emb_k = kpv;
+    return CSMPN_OK;
+}
+
+int csmpn_embed_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* vertex_feat,
+                              int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row, int32_t n_orders,
+                              int64_t n_rows, float* out, float* save_inputs, void* workspace, size_t workspace_bytes,
+                              uint32_t flags, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    RowIO io;
+    int rc = embed_io(id, blocks, vertex_feat, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, io);
+    if (rc) return rc;
+    Plan plan;
+    if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, n_rows, plan))) return rc;
+    io.y = out; io.save = save_inputs;
+    int channels = 0, attr = 0;
+    if (!plw_eligible(id, plan, MODE_PLAIN, false, io, &channels, &attr))
+        return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: shape not served by the wide parity-lane kernels");
+    (void)flags;
+    return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream, false);
+}
+
+int csmpn_embed_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
+                               int n_blocks, const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts,
+                               int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
+                               const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
+    const AlgId id = alg_id(metric, n);
+    if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
+    RowIO io;
+    int rc = embed_io(id, blocks, vertex_feat, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, io);
+    if (rc) return rc;
+    Plan plan;
+    if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, n_rows, plan))) return rc;
+    io.gy = g_out; io.saved = saved_inputs;
+    int channels = 0, attr = 0;
+    if (!plw_eligible(id, plan, MODE_PLAIN, true, io, &channels, &attr))
+        return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: shape not served by the wide parity-lane kernels (two blocks need saved inputs)");
+    (void)flags;
+    return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, false);
+}
+
 int csmpn_mvlinear_forward(int n, const float* x, const float* weight, const float* bias, int64_t rows,
                            int32_t in_features, int32_t out_features, int32_t subspaces, float* y, void* stream) {
     MvLinDesc P;

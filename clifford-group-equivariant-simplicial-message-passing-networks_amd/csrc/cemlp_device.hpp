@@ -126,6 +126,12 @@ struct RowIO {
     const float* plw_tabs;  // wide parity-lane kernels (cemlp_plw.hpp): rotation tables packed into the workspace
     float* plw_g1;          // ... backward: d/d(block-1 input) rows handed from the block-1 launch to the block-0 launch
     float* plw_part;        // ... backward: one slice of weight-gradient tiles per workgroup (added by plw_reduce_kernel)
+    // Fused simplex embedding (round 3, MODE_PLAIN of the wide parity-lane kernels; hulls_cssmpnn.py:96-125): row r is vertex
+    // order r % emb_nperm of simplex r / emb_nperm; its input channel v * emb_k + k is channel k of the embedded vertex
+    // row seg[0].a[emb_verts[r * emb_nv + v]] ([S, emb_k, D]); the emb_nperm consecutive output rows of a simplex are summed
+    // and stored as row r / emb_nperm of y; the backward reads d/d(out) there. emb_nperm = 0: off.
+    const int* emb_verts;
+    int emb_nperm, emb_nv, emb_k, pad4_;
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

@@ -336,7 +336,19 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 
     __syncthreads();
 
     const long ntiles = (io.rows + kPlRows - 1) / kPlRows;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Fused simplex embedding (MODE_PLAIN with io.emb_nperm > 0): a workgroup takes GT consecutive tiles = whole simplices
+    // (GT * 4 rows = lcm(4, emb_nperm)), so that the sum over the emb_nperm vertex orders of a simplex stays with one
+    // workgroup, in registers, in row order (no atomics).
+    const int emb_np = MODE == MODE_PLAIN ? io.emb_nperm : 0;
+    const int GT = emb_np == 6 ? 3 : 1;
+    const long ngroups = (ntiles + GT - 1) / GT;
+    for (long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    f4 eacc[kPlRows];
+#pragma unroll
+    for (int i = 0; i < kPlRows; ++i) eacc[i] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int gt_i = 0; gt_i < GT; ++gt_i) {
+        const long tile = grp * GT + gt_i;
+        if (tile >= ntiles) break;
         const long row = tile * kPlRows + ge.q;
         const bool valid = row < io.rows;
         const long lrow = valid ? row : 0;
@@ -374,7 +386,13 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 
                 else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
             } else {
                 (void)seg;
-                pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                if (emb_np) {   // channel ch = vertex ch / emb_k of this row's vertex order, its feature channel ch % emb_k
+                    const int v = (on ? ch : 0) / io.emb_k, kk = (on ? ch : 0) % io.emb_k;
+                    const long vr = io.emb_verts[lrow * io.emb_nv + v];
+                    pl_load<ALG>(x, io.seg[0].a + ((size_t)vr * io.emb_k + kk) * D, ge.s, on ? 1.0f : 0.0f);
+                } else {
+                    pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                }
             }
         };
         PlState<ALG> S;
@@ -442,6 +460,22 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 
                 }
                 if (cur >= 0) atomicAdd(io.agg + (long)cur * ROW + col, acc);
             }
+        } else if (emb_np) {
+            // rows of the group -> running sums of their simplices (slot = simplex index inside the group: <= 4 of them)
+            static_assert(MODE != MODE_PLAIN || 4 * NT >= ROW, "one 16-byte column piece per thread");
+            const int e = 4 * threadIdx.x;
+            if (e < ROW) {
+                const long s0 = grp * GT * kPlRows / emb_np;   // first simplex of the group
+                for (int r = 0; r < kPlRows; ++r) {
+                    const long rr = tile * kPlRows + r;
+                    if (rr < io.rows) {
+                        const int slot = (int)(rr / emb_np - s0);
+                        const f4 v = pl_ld4(stg + r * RS + e);
+#pragma unroll
+                        for (int i = 0; i < kPlRows; ++i) if (i == slot) eacc[i] += v;
+                    }
+                }
+            }
         } else {
             for (int r = 0; r < kPlRows; ++r) {
                 const long rr = tile * kPlRows + r;
@@ -451,6 +485,17 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 
             }
         }
         __syncthreads();                  // staging tile and exchange buffers free for the next tile
+    }
+    if (emb_np) {   // the group's simplices: one output row each
+        const int e = 4 * threadIdx.x;
+        const long s0 = grp * GT * kPlRows / emb_np, nsimp = io.rows / emb_np;
+        const int per_group = GT * kPlRows / emb_np;
+        if (e < ROW) {
+#pragma unroll
+            for (int i = 0; i < kPlRows; ++i)
+                if (i < per_group && s0 + i < nsimp) *reinterpret_cast<f4*>(io.y + (size_t)(s0 + i) * ROW + e) = eacc[i];
+        }
+    }
     }
 }
 
@@ -754,7 +799,8 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::WG_PER_CU_BWD) cemlp_plw_bwd_
         if constexpr (BLK == 1) {
             float gout[DL], in1[DL], gy[DL];
             {
-                const long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                if (MODE == MODE_PLAIN && io.emb_nperm) grow = lrow / io.emb_nperm;   // fused embedding: the simplex's row
                 pl_load<ALG>(gout, io.gy + (size_t)grow * ROW + cch, ge.s, von);
             }
             pl_load<ALG>(in1, io.saved + (size_t)lrow * ROW + cch, ge.s, von);
@@ -812,14 +858,21 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::WG_PER_CU_BWD) cemlp_plw_bwd_
                     else pl_load<ALG>(x, io.seg[1].a + (size_t)lrow * ROW + co, ge.s, on ? scale : 0.0f);
                 } else {
                     (void)seg;
-                    pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                    if (io.emb_nperm) {   // fused embedding: see the forward
+                        const int v = (on ? ch : 0) / io.emb_k, kk = (on ? ch : 0) % io.emb_k;
+                        const long vr = io.emb_verts[lrow * io.emb_nv + v];
+                        pl_load<ALG>(x, io.seg[0].a + ((size_t)vr * io.emb_k + kk) * D, ge.s, on ? 1.0f : 0.0f);
+                    } else {
+                        pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
+                    }
                 }
             };
             float g1[DL], gy0[DL];
             if constexpr (CF::NBLK > 1) {
                 pl_load<ALG>(g1, io.plw_g1 + (size_t)lrow * ROW + cch, ge.s, von);
             } else {   // single block: d/d(out) comes from the caller
-                const long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                long grow = MODE == MODE_EDGE ? (long)(valid ? i_dst : 0) : lrow;
+                if (MODE == MODE_PLAIN && io.emb_nperm) grow = lrow / io.emb_nperm;
                 pl_load<ALG>(g1, io.gy + (size_t)grow * ROW + cch, ge.s, von);
             }
             {

@@ -273,6 +273,25 @@ typedef struct csmpn_vertex_block {
 int csmpn_simplex_rows(int n, const csmpn_vertex_block* blocks, int n_blocks, const int64_t* verts, int64_t n_rows,
                        int32_t verts_per_row, int64_t n_feature_rows, float* out, void* stream);
 
+/* Fused simplex feature embedding (round 3; hulls_cssmpnn.py:96-125: vertex features of every d-simplex in all (d+1)!
+ * vertex orders -> CEMLP -> sum over the orders), for the shapes the wide parity-lane kernels serve as standalone CEMLPs
+ * (Cl(5,0) / Cl(4,1), 16 / 24 / 28 / 32 output channels, at most 8 input channels = verts_per_row * channels_per_vertex);
+ * every other shape returns CSMPN_ERR_UNSUPPORTED (the caller composes csmpn_simplex_rows + csmpn_cemlp_* + a sum).
+ *   vertex_feat [n_feature_rows, channels_per_vertex, D]  the embedded (full multivector) features of every batch row;
+ *   verts [n_rows, verts_per_row] int32: row r = vertex order r % n_orders of simplex r / n_orders (n_rows = n_simplices * n_orders);
+ *   out [n_simplices, O, D]: out[s] = sum over its n_orders rows of CEMLP(concat_v vertex_feat[verts[r][v]]).
+ * Neither the [n_rows, I, D] input rows nor the [n_rows, O, D] per-order outputs exist in memory; the sum is taken in
+ * registers in row order (no atomics). n_orders in {1, 2, 6}. save_inputs / saved_inputs as for csmpn_cemlp_* (rows = n_rows).
+ * backward: d/d(parameters) only (the features are data); g_out [n_simplices, O, D]. */
+int csmpn_embed_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
+                              const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row,
+                              int32_t n_orders, int64_t n_rows, float* out, float* save_inputs, void* workspace,
+                              size_t workspace_bytes, uint32_t flags, void* stream);
+int csmpn_embed_cemlp_backward(const float* metric_host, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
+                               int n_blocks, const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts,
+                               int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
+                               const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
+
 /* Scalar readout + loss of the convex-hulls model (hulls_cssmpnn.py:93,155-164):
  *   pred_g = mean_{s in graph g} (sum_c weight[c * weight_stride] * x[s][c][0]) + bias,  loss_g = (pred_g - target_g)^2
  * weight points at MVLinear.weight[0] (out_features = 1; weight_stride = n+1 with subspaces, else 1),
