@@ -16,6 +16,7 @@
 #include "launch.hpp"
 #include "rl_launch.hpp"
 #include "cl_launch.hpp"
+#include "cm_launch.hpp"
 #include "pl_launch.hpp"
 #include "plw_launch.hpp"
 
@@ -642,6 +643,27 @@ bool cl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return true;
 }
 
+// channel-MFMA kernels (cemlp_cm.hpp): Cl(3,0), two blocks of 16 channels, the EGCL attribute widths of S2.
+// CSMPN_NO_CM=1 leaves these shapes to the row-per-lane kernels (A/B measurements, parity tests of both paths).
+bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
+    static const bool off = getenv("CSMPN_NO_CM") && atoi(getenv("CSMPN_NO_CM"));
+    if (off || id != ALG_N3) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    const int ch = C.b[0].O;
+    for (int k = 0; k < C.nblk; ++k) {
+        if (C.b[k].O != ch || !C.b[k].w1_sub) return false;
+        if (k > 0 && C.b[k].I != ch) return false;
+    }
+    if (mode == MODE_EDGE && (io.seg[0].ch != ch || C.b[0].I != ch + (io.nseg > 1 ? io.seg[1].ch : 0))) return false;
+    if (mode == MODE_NODE && (io.seg[0].ch != ch || io.seg[1].ch != ch || C.b[0].I != 2 * ch + (io.nseg > 2 ? io.seg[2].ch : 0))) return false;
+    if (mode != MODE_EDGE && mode != MODE_NODE) return false;
+    if (bwd && !io.saved) return false;
+    *channels = ch;
+    *i0 = C.b[0].I;
+    return has_cemlp_cm_n3(mode, C.nblk, ch, C.b[0].I, bwd);
+}
+
 // parity-lane kernels (cemlp_pl.hpp): Cl(5,0) / Cl(4,1), two blocks of 8 channels, the EGCL attribute widths of S3
 bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* i0) {
     static const bool off = getenv("CSMPN_NO_PL") && atoi(getenv("CSMPN_NO_PL"));
@@ -760,6 +782,20 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             static const bool debug_cl = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_cl) fprintf(stderr, "[csmpn] cl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
             HIP_TRY(launch_cemlp_cl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
+            if (handled) return CSMPN_OK;
+        }
+    }
+    {
+        int channels = 0, i0 = 0;
+        if (cm_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
+            const long tiles = (io.rows + 15) / 16;   // tile t (16 rows) belongs to wave t % (4 grid)
+            const long cap = kCmMaxFwdGroups;
+            const long groups = (tiles + 3) / 4;
+            const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            bool handled = false;
+            static const bool debug_cm = getenv("CSMPN_DEBUG") != nullptr;
+            if (debug_cm) fprintf(stderr, "[csmpn] cm mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
+            HIP_TRY(launch_cemlp_cm_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
             if (handled) return CSMPN_OK;
         }
     }

@@ -1,0 +1,15 @@
+// Host-visible launchers of the channel-MFMA kernels (cemlp_cm.hpp), one set per compiled algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cemlp_device.hpp"
+
+namespace csmpn {
+constexpr int kCmMaxFwdGroups = 512;   // 4-wave workgroups of a forward launch: two per CU
+#define CSMPN_DECLARE_CM(tag)                                                                                  \
+    bool has_cemlp_cm_##tag(int mode, int nblk, int channels, int i0, bool bwd);                                \
+    hipError_t launch_cemlp_cm_##tag(int mode, int nblk, int channels, int i0, bool bwd, unsigned grid,         \
+                                     hipStream_t st, const DevCemlp& C, const RowIO& io, bool* handled);
+CSMPN_DECLARE_CM(n3)
+
+}  // namespace csmpn

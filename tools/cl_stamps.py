@@ -17,7 +17,11 @@ BWD = ["setup(stage tables)", "loads(wait)", "r:W1 mix", "r:silu", "r:linR/L", "
        "b:layernorm", "b:linL^T", "b:gp", "b:norm", "b:linR^T", "b:wgradRL(mfma)", "b:silu", "b:wgradW1(mfma)",
        "b:W1^T+store/scatter", "end-of-kernel sums"]
 
-def main(workload="S1"):
+CM_FWD = ["setup(stage tables)", "loads(wait)", "W1 mix b0", "silu b0", "linR/L b0", "norm+gp b0", "layernorm b0", "", "W1 mix b1",
+          "silu b1", "linR/L b1", "norm+gp b1", "layernorm b1", "", "issue next + store/scatter"]
+
+
+def main(workload="S1", family="cl"):
     dev = torch.device("cuda:0")
     metric, C, N, E = bench.WORKLOADS[workload]
     (h, ei, ea, na), _ = bench.make_inputs(metric, C, N, E, 0, E, dev)
@@ -49,10 +53,10 @@ def main(workload="S1"):
         v = st.cpu().tolist()
         waves, tot = v[24], sum(v[:24])
         print(f"== {name}: {waves} waves, {tot / max(waves,1) / 1e3:.1f} kcycles per wave")
-        names = FWD if name.endswith("fwd") else BWD
+        names = (CM_FWD if family == "cm" else FWD) if name.endswith("fwd") else BWD
         for i, nm in enumerate(names):
-            if v[i]:
+            if v[i] and nm:
                 print(f"   {nm:24s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "S1")
+    main(sys.argv[1] if len(sys.argv) > 1 else "S1", sys.argv[2] if len(sys.argv) > 2 else "cl")

@@ -1,8 +1,9 @@
 #!/bin/bash
 # PMC passes (no trace domains) over tools/cl_stage4.py; per-kernel averages -> gpurun_out/r03_<tag>_pmcx.json
+#   tools/pmc_cl.sh <tag> [workload = S1] [kernel-name filter = cemlp_cl]
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-TAG=${1:-x}; WL=${2:-S1}
+TAG=${1:-x}; WL=${2:-S1}; FILTER=${3:-cemlp_cl}
 OUT=gpurun_out/pmcx_$TAG
 rm -rf $OUT; mkdir -p $OUT
 P="python3 tools/cl_stage4.py $WL"
@@ -16,7 +17,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for fn in glob.glob("$OUT/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         k = r["Kernel_Name"]
-        if "cemlp_cl" not in k: continue
+        if "$FILTER" not in k: continue
         k = k.replace("csmpn::Alg<3, 0u>, ", "").replace("(csmpn::DevCemlp, csmpn::RowIO)", "").replace("void csmpn::", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 summary = {k: {c: int(round(v / cnt[k][c])) for c, v in sorted(d.items())} for k, d in acc.items()}
