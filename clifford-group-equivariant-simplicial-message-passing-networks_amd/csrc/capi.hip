@@ -556,8 +556,21 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     size_t clf = cemlp_cl_partial_floats_n3(MODE_EDGE, nblk, ch, i0);
     const size_t cln = cemlp_cl_partial_floats_n3(MODE_NODE, nblk, ch, i0);
     clf = cln > clf ? cln : clf;
-    const size_t cl = clf * sizeof(float) * kClMaxBwdGroups;
+    size_t cl = clf * sizeof(float) * kClMaxBwdGroups;
+    // channel-MFMA backward (cemlp_cm.hpp): the same region and slice layout
+    size_t cmf = cemlp_cm_partial_floats_n3(MODE_EDGE, nblk, ch, i0);
+    const size_t cmn = cemlp_cm_partial_floats_n3(MODE_NODE, nblk, ch, i0);
+    cmf = cmn > cmf ? cmn : cmf;
+    const size_t cm = cmf * sizeof(float) * kCmSliceCap;
+    cl = cm > cl ? cm : cl;
     return cl > rl ? cl : rl;
+}
+// The channel-MFMA backward (cemlp_cm.hpp) is correct but slower than the row-per-lane backward it would replace
+// (measurements at CM_BWD_OCC in cemlp_cm.hpp): CSMPN_CM_BWD=1 selects it. Read ONCE per process: the size of the saved
+// region the caller allocates (csmpn_cemlp_saved_floats_per_row) depends on it and must not change under a live plan.
+bool cm_bwd_enabled() {
+    static const bool on = getenv("CSMPN_CM_BWD") && atoi(getenv("CSMPN_CM_BWD"));
+    return on;
 }
 // the (row, channel)-per-lane backward hands d/d(block-1 input) from its block-1 launch to its block-0 launch through
 // one more [rows, C, D] region behind the saved block inputs (as the wide parity-lane kernels do)
@@ -565,7 +578,8 @@ bool cl_shape(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 3 || nblk != 2) return false;
     const int ch = blocks[0].out_features, i0 = blocks[0].in_features;
     if (blocks[1].out_features != ch || blocks[1].in_features != ch) return false;
-    return has_cemlp_cl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_cl_n3(MODE_NODE, nblk, ch, i0);
+    if (has_cemlp_cl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_cl_n3(MODE_NODE, nblk, ch, i0)) return true;
+    return cm_bwd_enabled() && (has_cemlp_cm_n3(MODE_EDGE, nblk, ch, i0, true) || has_cemlp_cm_n3(MODE_NODE, nblk, ch, i0, true));
 }
 
 // bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
@@ -661,7 +675,13 @@ bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     if (bwd && !io.saved) return false;
     *channels = ch;
     *i0 = C.b[0].I;
-    return has_cemlp_cm_n3(mode, C.nblk, ch, C.b[0].I, bwd);
+    if (!has_cemlp_cm_n3(mode, C.nblk, ch, C.b[0].I, bwd)) return false;
+    if (bwd) {
+        if (!cm_bwd_enabled()) return false;   // opt-in: slower than the row-per-lane backward
+        const size_t pb = cemlp_cm_partial_floats_n3(mode, C.nblk, ch, C.b[0].I) * sizeof(float) * kCmSliceCap;
+        if (!plan.workspace || plan.workspace_bytes < pb) return false;
+    }
+    return true;
 }
 
 // parity-lane kernels (cemlp_pl.hpp): Cl(5,0) / Cl(4,1), two blocks of 8 channels, the EGCL attribute widths of S3
@@ -789,9 +809,14 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         int channels = 0, i0 = 0;
         if (cm_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
             const long tiles = (io.rows + 15) / 16;   // tile t (16 rows) belongs to wave t % (4 grid)
-            const long cap = kCmMaxFwdGroups;
+            const long cap = bwd ? kCmMaxBwdGroups : kCmMaxFwdGroups;
             const long groups = (tiles + 3) / 4;
             const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+            if (bwd) {
+                const size_t pb = cemlp_cm_partial_floats_n3(mode, plan.C.nblk, channels, i0) * sizeof(float) * kCmSliceCap;
+                io.rl_partials = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb) & ~(size_t)15));
+                io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // see csmpn_cemlp_saved_floats_per_row
+            }
             bool handled = false;
             static const bool debug_cm = getenv("CSMPN_DEBUG") != nullptr;
             if (debug_cm) fprintf(stderr, "[csmpn] cm mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);

@@ -7,6 +7,7 @@ reference's own float32 CPU run as the yardstick: the HIP result must be within
 max(1e-5, 4 x the error of the reference's fp32 run) of the fp64 truth.
 """
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -389,6 +390,23 @@ def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
         # ... and with the summation order fixed the same shapes are held to the default factor 4, element-wise check included
         with deterministic_aggregation():
             _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=N + E, residual=residual, neg_scale=0.02, attr_grad=True, slack=4.0)
+
+
+def test_channel_mfma_backward_opt_in(pkg):
+    """The channel-MFMA backward (cemlp_cm.hpp; not dispatched by default - slower than the row-per-lane backward it would
+    replace) stays parity-green: the 16-channel Cl(3,0) shape cases again in a child process with CSMPN_CM_BWD=1 (the
+    switch is read once per process), and the library's dispatch log must show that kernel family taking the backward."""
+    import subprocess
+    env = dict(os.environ, CSMPN_CM_BWD="1", CSMPN_DEBUG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-m", "gpu", "-x", "-k",
+                        "test_lane_kernel_shapes and metric1-16"],
+                       env=env, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = r.stderr[:1500] + "\n...\n" + (r.stdout + r.stderr)[-2500:]
+    assert r.returncode == 0, tail
+    log = r.stdout + r.stderr
+    assert "cm mode=1 bwd=1" in log and "cm mode=2 bwd=1" in log, "the channel-MFMA backward was not dispatched\n" + tail
+    assert " passed" in log and "failed" not in log, tail
 
 
 def test_wide_kernels_reproducible_for_fixed_inputs(pkg):
