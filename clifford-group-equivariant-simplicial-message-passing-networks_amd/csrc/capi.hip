@@ -496,7 +496,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
 // Deterministic mode on the general kernels: every workgroup of a backward launch accumulates into its own zeroed copy of
 // the gradient tensors ([kDetGroups, slice] floats at the end of the workspace, reference layouts back to back);
 // det_reduce_kernel adds the copies in a fixed order.
-constexpr int kDetGroups = 128;
+constexpr int kDetGroups = 512;
 int det_slice_floats_of(const csmpn_block_params* blocks, int nblk, int G, int P) {
     int m = 0;
     for (int k = 0; k < nblk; ++k)
@@ -855,7 +855,12 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     float* det_slices = nullptr;
     DetMap det_map;
     int det_total = 0;
-    if (io.row_store && bwd) {   // per-workgroup copies of the gradient tensors at the end of the workspace
+    // Per-workgroup copies of the gradient tensors at the end of the workspace: always in deterministic mode, and (round 3)
+    // for every backward of the small algebras - the parameter-gradient atomics of ALL row tiles onto one copy were the
+    // bulk of the md17-width backward (M32 node stage 1.04 -> 0.53 ms with private copies); CSMPN_NO_SLICED_GRADS=1: off.
+    static const bool no_sliced = getenv("CSMPN_NO_SLICED_GRADS") && atoi(getenv("CSMPN_NO_SLICED_GRADS"));
+    const bool sliced = bwd && (io.row_store || (!no_sliced && (id == ALG_N2 || id == ALG_N3) && !plan.ps && plan.var != VAR_GLOBAL));
+    if (sliced) {
         const int G = (id == ALG_N2) ? 3 : 4, P = n_paths(id);   // det_general: n <= 3
         det_map.n = 0;
         for (int k = 0; k < plan.C.nblk; ++k) {
@@ -871,9 +876,13 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         }
         det_map.total = det_total;
         det_bytes = (size_t)det_total * sizeof(float) * kDetGroups + 256;
-        if (!plan.workspace || plan.workspace_bytes < det_bytes)
-            return fail(CSMPN_ERR_INVALID, "workspace too small for the deterministic backward: %zu < %zu", plan.workspace_bytes, det_bytes);
-        det_slices = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - det_bytes) & ~(size_t)255));
+        if (!plan.workspace || plan.workspace_bytes < det_bytes) {
+            if (io.row_store)
+                return fail(CSMPN_ERR_INVALID, "workspace too small for the deterministic backward: %zu < %zu", plan.workspace_bytes, det_bytes);
+            det_bytes = 0;   // a caller's smaller workspace: atomics onto the one copy
+        } else {
+            det_slices = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - det_bytes) & ~(size_t)255));
+        }
     }
     // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
     if (need_pack) {
