@@ -322,6 +322,35 @@ def _reduce_scatter_rows(part, full, group):
         part.copy_(full.chunk(w, dim=0)[r])
 
 
+class _Pending:
+    """Handle of a collective in flight (async_op=True): wait() orders the current stream behind it, then runs the
+    epilogue the blocking form would have run (gloo's reduce-scatter stand-in slices the all-reduced rows)."""
+
+    def __init__(self, works, epilogue=None):
+        self.works, self.epilogue = works, epilogue
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        if self.epilogue is not None:
+            self.epilogue()
+
+
+def _all_gather_rows_async(full, part, group) -> _Pending:
+    if _fused_collectives(group):
+        return _Pending([dist.all_gather_into_tensor(full, part, group=group, async_op=True)])
+    chunks = list(full.chunk(dist.get_world_size(group), dim=0))
+    return _Pending([dist.all_gather(chunks, part, group=group, async_op=True)])
+
+
+def _reduce_scatter_rows_async(part, full, group) -> _Pending:
+    if _fused_collectives(group):
+        return _Pending([dist.reduce_scatter_tensor(part, full, op=dist.ReduceOp.SUM, group=group, async_op=True)])
+    w, r = dist.get_world_size(group), dist.get_rank(group)
+    return _Pending([dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group, async_op=True)],
+                    lambda: part.copy_(full.chunk(w, dim=0)[r]))
+
+
 def agree_all(local_ok: bool, group=None, device=None) -> bool:
     """True iff the condition holds on EVERY rank (all-reduce MIN of a flag). For choices that change which
     collectives a rank issues: they must come out the same everywhere, or the ranks post mismatched collectives."""
@@ -354,6 +383,16 @@ class DstPlan:
         self.csr = backend.build_csr(edge_index[:, self.edge_ids].contiguous(), n_nodes)
         self.deg = self.csr.deg     # every edge into an owned node is local: the local in-degree is the global one
         self.n_nodes = n_nodes
+        # The owned edges split by SOURCE locality (positions in the owned list): an edge whose source is owned too needs
+        # no row of another rank - the layer's edge stage on these runs under the all-gather of the previous layer's
+        # output, their d/dh stays out of the reduce-scatter (DstPartitionedStack(overlap=True))
+        src_own = edge_index[0, self.edge_ids]
+        loc = (src_own >= self.lo) & (src_own < self.hi)
+        self.idx_loc = torch.nonzero(loc, as_tuple=False).squeeze(1)
+        self.idx_rem = torch.nonzero(~loc, as_tuple=False).squeeze(1)
+        self._split = None
+        self._backend = backend
+        self._edge_index_owned = edge_index[:, self.edge_ids]
         # padded position of every node row / node row (or N = the zero row) of every padded position
         pos = torch.empty(n_nodes, dtype=torch.int64)
         src = torch.full((self.world * self.per,), n_nodes, dtype=torch.int64)
@@ -369,6 +408,14 @@ class DstPlan:
             cnt[self.rank] = int(self.edge_ids.numel())
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
             self.edges_per_rank = cnt.tolist()
+
+    def split(self):
+        """(csr of the local-source edges, csr of the remote-source edges), built on first use."""
+        if self._split is None:
+            ei = self._edge_index_owned
+            self._split = (self._backend.build_csr(ei[:, self.idx_loc].contiguous(), self.n_nodes),
+                           self._backend.build_csr(ei[:, self.idx_rem].contiguous(), self.n_nodes))
+        return self._split
 
     # ---- rows between the layouts (one index kernel each)
     def pad_slice(self, rows_loc):
@@ -513,6 +560,145 @@ class _DstPartStackFn(torch.autograd.Function):
         return (gh, g_ea_total, g_na, None, None, None, None, None, *views_all)
 
 
+class _DstPartStackOverlapFn(torch.autograd.Function):
+    """_DstPartStackFn with the collectives of the chain hidden under edge work (world > 1). Every layer's edge stage
+    runs in two launches: the owned edges whose source is owned too (they read rows of the own slice only) and the rest.
+    Forward: the all-gather of layer k's output slice is in flight while layer k + 1 runs its local-source edges on the
+    slice it already has; the remote-source edges follow the wait. Backward: the remote-source edges go first, the
+    reduce-scatter of THEIR d/dh (the only part with rows of other ranks) travels while the local-source edges run; the
+    local part lands on owned rows and is added behind the wait. Same results as the blocking chain up to the order of
+    two float additions per row."""
+
+    @staticmethod
+    def forward(ctx, h, edge_attr_local, node_attr, specs, plan: DstPlan, backend, group, counts, *params):
+        lo, hi = plan.lo, plan.hi
+        csr_l, csr_r = plan.split()
+        ea_l = None if edge_attr_local is None else edge_attr_local.index_select(0, plan.idx_loc)
+        ea_r = None if edge_attr_local is None else edge_attr_local.index_select(0, plan.idx_rem)
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        deg_loc = plan.deg[lo:hi].contiguous()
+        hs, aggs, st = [], [], []
+        x = h.contiguous()
+        pending, padded, x_own = None, None, None
+        off = 0
+        for spec, cnt in zip(specs, counts):
+            lp = params[off:off + cnt]
+            off += cnt
+            ne = spec.edge.nblk * ops.NP
+            pe, pn = lp[:ne], lp[ne:]
+            if pending is None:
+                agg_l, st_l = backend.edge_forward(spec, csr_l, x, ea_l, pe)
+            else:
+                # rows outside [lo, hi) of x_own are never read by the local-source edges
+                agg_l, st_l = backend.edge_forward(spec, csr_l, x_own, ea_l, pe)
+                pending.wait()
+                x = plan.from_padded(padded)
+                pending = None
+            agg_r, st_r = backend.edge_forward(spec, csr_r, x, ea_r, pe)
+            agg = agg_l + agg_r                                                       # complete on [lo, hi)
+            out_loc, st_n = backend.node_forward(spec, deg_loc, x[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn)
+            hs.append(x); aggs.append(agg); st.append((st_l, st_r, st_n))
+            padded = out_loc.new_empty((plan.world * plan.per,) + tuple(out_loc.shape[1:]))
+            pending = _all_gather_rows_async(padded, plan.pad_slice(out_loc), group)
+            x_own = out_loc.new_zeros((plan.n_nodes,) + tuple(out_loc.shape[1:]))
+            x_own[lo:hi] = out_loc
+        pending.wait()
+        x = plan.from_padded(padded)
+        ctx.st = st
+        ctx.specs, ctx.plan, ctx.backend, ctx.group, ctx.counts = specs, plan, backend, group, counts
+        ctx.has_ea, ctx.has_na = edge_attr_local is not None, node_attr is not None
+        ctx.mask = [p is not None for p in params]
+        ctx.n_layers = len(specs)
+        saved = hs + aggs + ([ea_l, ea_r] if ctx.has_ea else []) + ([node_attr] if ctx.has_na else [])
+        ctx.save_for_backward(*saved, *[p for p in params if p is not None])
+        return x
+
+    @staticmethod
+    def backward(ctx, gout):
+        specs, plan, backend, group, counts = ctx.specs, ctx.plan, ctx.backend, ctx.group, ctx.counts
+        L = ctx.n_layers
+        saved = list(ctx.saved_tensors)
+        hs, aggs = saved[:L], saved[L:2 * L]
+        pos = 2 * L
+        ea_l = ea_r = node_attr = None
+        if ctx.has_ea:
+            ea_l, ea_r = saved[pos], saved[pos + 1]; pos += 2
+        if ctx.has_na:
+            node_attr = saved[pos]; pos += 1
+        it = iter(saved[pos:])
+        params = [next(it) if m else None for m in ctx.mask]
+        lo, hi = plan.lo, plan.hi
+        csr_l, csr_r = plan.split()
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        deg_loc = plan.deg[lo:hi].contiguous()
+        offs = [0]
+        for cnt in counts:
+            offs.append(offs[-1] + cnt)
+        g_loc = gout[lo:hi].contiguous()
+        views_all = [None] * len(params)
+        g_ea_l_tot = g_ea_r_tot = g_na_loc_total = None
+
+        def acc(a, b):
+            return b if a is None else (a if b is None else a + b)
+
+        for k in range(L - 1, -1, -1):
+            spec = specs[k]
+            lp = params[offs[k]:offs[k + 1]]
+            ne = spec.edge.nblk * ops.NP
+            pe, pn = lp[:ne], lp[ne:]
+            h, agg = hs[k], aggs[k]
+            st_l, st_r, st_n = ctx.st[k]
+            gh_node, g_agg_loc, g_na_loc, views_n = backend.node_backward(
+                spec, deg_loc, h[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn, g_loc,
+                ctx.needs_input_grad[2], st_n)
+            g_agg = torch.zeros_like(agg)
+            g_agg[lo:hi] = g_agg_loc
+            gh_r = torch.zeros_like(h)             # +g -> owned targets, -g -> sources on OTHER ranks
+            g_ea_r, views_r = backend.edge_backward(spec, csr_r, h, ea_r, pe, g_agg, gh_r, ctx.needs_input_grad[1], st_r)
+            g_pad = gh_r.new_empty((plan.per,) + tuple(gh_r.shape[1:]))
+            pending = _reduce_scatter_rows_async(g_pad, plan.to_padded(gh_r), group)
+            gh_l = torch.zeros_like(h)             # both ends owned: rows of [lo, hi) only
+            g_ea_l, views_l = backend.edge_backward(spec, csr_l, h, ea_l, pe, g_agg, gh_l, ctx.needs_input_grad[1], st_l)
+            views_e = [acc(a, b) for a, b in zip(views_l, views_r)]
+            for i, v in enumerate(list(views_e) + list(views_n)):
+                views_all[offs[k] + i] = v
+            g_ea_l_tot, g_ea_r_tot = acc(g_ea_l_tot, g_ea_l), acc(g_ea_r_tot, g_ea_r)
+            g_na_loc_total = acc(g_na_loc_total, g_na_loc)
+            pending.wait()
+            g_loc = g_pad[:hi - lo] + gh_l[lo:hi] + gh_node
+        gh = None
+        if ctx.needs_input_grad[0]:
+            padded = g_loc.new_empty((plan.world * plan.per,) + tuple(g_loc.shape[1:]))
+            _all_gather_rows(padded, plan.pad_slice(g_loc), group)
+            gh = plan.from_padded(padded)
+        g_ea_total = None
+        if g_ea_l_tot is not None or g_ea_r_tot is not None:
+            ref = g_ea_l_tot if g_ea_l_tot is not None else g_ea_r_tot
+            g_ea_total = ref.new_zeros((plan.edge_ids.numel(),) + tuple(ref.shape[1:]))
+            if g_ea_l_tot is not None:
+                g_ea_total[plan.idx_loc] = g_ea_l_tot
+            if g_ea_r_tot is not None:
+                g_ea_total[plan.idx_rem] = g_ea_r_tot
+        live = [v for v in views_all if v is not None]
+        if live:
+            flat = torch.cat([v.reshape(-1) for v in live])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off, red = 0, []
+            for v in views_all:
+                if v is None:
+                    red.append(None)
+                else:
+                    red.append(flat[off:off + v.numel()].view(v.shape))
+                    off += v.numel()
+            views_all = red
+        g_na = None
+        if g_na_loc_total is not None:
+            g_na = torch.zeros_like(node_attr)
+            g_na[lo:hi] = g_na_loc_total
+            dist.all_reduce(g_na, op=dist.ReduceOp.SUM, group=group)
+        return (gh, g_ea_total, g_na, None, None, None, None, None, *views_all)
+
+
 class DstPartitionedEGCL(torch.nn.Module):
     """Wraps an EGCL module (partitioning B). `plan(edge_index, n_nodes)` takes the WHOLE edge list
     (replicated topology); forward takes the whole h / node_attr and this rank's rows of edge_attr
@@ -538,14 +724,16 @@ class DstPartitionedEGCL(torch.nn.Module):
 class DstPartitionedStack(torch.nn.Module):
     """L chained EGCL layers on ONE destination partition of the complex: h stays resident, every
     layer costs one all-gather forward and one reduce-scatter backward, the parameter gradients of all layers one
-    all-reduce. All layers share edge_attr / node_attr, as the reference's models do (hulls_cssmpnn.py:89-94)."""
+    all-reduce. All layers share edge_attr / node_attr, as the reference's models do (hulls_cssmpnn.py:89-94).
+    overlap=True: the collectives travel under the edges whose source is owned too (two edge launches per stage)."""
 
-    def __init__(self, layers, backend=ops.HipBackend, group=None, balance=True):
+    def __init__(self, layers, backend=ops.HipBackend, group=None, balance=True, overlap=False):
         super().__init__()
         self.layers = torch.nn.ModuleList(layers)
         self.backend = backend
         self.group = group
         self.balance = balance
+        self.overlap = overlap     # collectives in flight under the local-source edges (_DstPartStackOverlapFn)
 
     def plan(self, edge_index, n_nodes) -> DstPlan:
         return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance)
@@ -557,8 +745,8 @@ class DstPartitionedStack(torch.nn.Module):
             params += lp
             counts.append(len(lp))
             specs.append(layer.spec())
-        return _DstPartStackFn.apply(h, edge_attr_local, node_attr, tuple(specs), plan, self.backend, self.group,
-                                     tuple(counts), *params)
+        fn = _DstPartStackOverlapFn if (self.overlap and plan.world > 1) else _DstPartStackFn
+        return fn.apply(h, edge_attr_local, node_attr, tuple(specs), plan, self.backend, self.group, tuple(counts), *params)
 
 
 class GraphedDstStep:

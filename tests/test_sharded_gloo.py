@@ -168,7 +168,7 @@ def test_dst_partitioned_matches_unsharded(aggr, world):
             assert v < 5e-5, (rank, k, v)
 
 
-def _worker_stack(rank, world, port, q):
+def _worker_stack(rank, world, port, q, overlap=False):
     """Three chained layers on one destination partition: output, d/dh, attribute and every
     parameter gradient equal the unsharded chain; N not divisible by the world size, a hub node, an isolated node."""
     sys.path.insert(0, ROOT)
@@ -189,7 +189,7 @@ def _worker_stack(rank, world, port, q):
         ei[1, :60] = N - 2                   # hub near the end
         ei[:, ei[1] == 5] = torch.tensor([[1], [6]])   # node 5 receives nothing (isolated as a target)
         gout = torch.randn(N, 4, 8, generator=torch.Generator().manual_seed(4))
-        stack = sharded.DstPartitionedStack(layers, backend=OracleBackend)
+        stack = sharded.DstPartitionedStack(layers, backend=OracleBackend, overlap=overlap)
         plan = stack.plan(ei, N)
         hh = h.clone().requires_grad_(True)
         eal = ea[plan.edge_ids].clone().requires_grad_(True)
@@ -216,12 +216,13 @@ def _worker_stack(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_dst_partitioned_stack_matches_unsharded_chain(world):
+@pytest.mark.parametrize("world,overlap", [(2, False), (3, False), (2, True), (3, True)])
+def test_dst_partitioned_stack_matches_unsharded_chain(world, overlap):
+    """overlap=True: the collectives of the chain in flight under the local-source edges (two edge launches per stage)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_stack, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_stack, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]

@@ -150,6 +150,63 @@ def test_dst_partitioned_hip_matches_unsharded(metric, C):
             assert v < 2e-5, (rank, k, v)
 
 
+def _worker_stack_overlap(rank, world, port, q):
+    """Two chained layers, partitioning B with the collectives in flight under the local-source edges (HIP backend)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        from oracle import ref_path as O
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        metric, C = (1.0, 1.0, 1.0), 8
+        alg = pkg.CliffordAlgebra(metric)
+        layers = [pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr=a).to(dev) for a in ("mean", "sum")]
+        N, E = 501, 7001
+        h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=1))
+        gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(2)).to(dev)
+        stack = sharded.DstPartitionedStack(layers, overlap=True)
+        plan = stack.plan(ei, N)
+        assert plan.idx_loc.numel() > 0 and plan.idx_rem.numel() > 0
+        eal = ea[plan.edge_ids].contiguous().requires_grad_(True)
+        hh = h.clone().requires_grad_(True)
+        y = stack(hh, plan, eal, na)
+        params = [p for l in layers for p in l.parameters()]
+        gs = torch.autograd.grad(y, [hh, eal] + params, gout)
+        h2, ea2 = h.clone().requires_grad_(True), ea.clone().requires_grad_(True)
+        x = h2
+        for l in layers:
+            x = l(x, ei, ea2, na)
+        g2 = list(torch.autograd.grad(x, [h2, ea2] + params, gout))
+        g2[1] = g2[1][plan.edge_ids]
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        res = {"y": rel(y, x)}
+        for i, (a, b) in enumerate(zip(gs, g2)):
+            res[f"g{i}"] = rel(a, b)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dst_partitioned_stack_overlap_hip():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stack_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, res in results:
+        for k, v in res.items():
+            assert v < 5e-5, (rank, k, v)
+
+
 # ----------------------------------------------------------------------------- data parallel over graphs
 
 def _worker_ddp(rank, world, port, q):
