@@ -34,10 +34,15 @@ namespace csmpn {
 
 constexpr int kCmWaves = 4;   // waves per workgroup
 constexpr int kCmRows = 16;   // rows per wave tile
+constexpr int kCmFwdStageRows = 8;   // rows of the forward's scatter staging tile (two passes per wave tile)
 
 // Scheduling fence between the per-channel sections of the backward: left alone, the scheduler interleaves the four
 // channels of a lane for instruction-level parallelism and quadruples the live temporaries (2 KB of scratch per lane).
 #define CM_FENCE() __builtin_amdgcn_sched_barrier(0)
+// Compiler barrier between 16-byte vector stores into a staging buffer and the float reads of the same bytes (and back):
+// the two access types carry different type-based alias information, and the compiler did move the second half's
+// stores in front of the first half's reads (found by the 101-edge parity case). Costs no instruction.
+#define CM_LDS_ORDER() asm volatile("" ::: "memory")
 // Workgroups per CU the backward is compiled for. Measured (round 3): the live set of a backward tile is ~330 registers
 // (y, R, d/d(gp), d/dz: 128; weight-gradient tiles + parameter sums: 76; one channel's product backward: ~110-150), so
 // a 256-register build spills 1.8 KB per lane (S2 edge backward 10.9 ms); at 512 registers it still spills 0.6 KB and
@@ -45,6 +50,9 @@ constexpr int kCmRows = 16;   // rows per wave tile
 // (CSMPN_CM_BWD=1 selects it; parity-tested); DESIGN.md 4.1c.
 #ifndef CM_BWD_OCC
 #define CM_BWD_OCC 1
+#endif
+#ifndef CM_FWD_OCC
+#define CM_FWD_OCC 3   // workgroups per CU the forward is compiled for (~160 registers, <= 53 KB of LDS)
 #endif
 
 // block K of a CEMLP in mode MODE with NA attribute channels: its 16-slot input chunks and its LDS tables (float offsets)
@@ -280,6 +288,7 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
             cm_silu<ALG>(yy, zz, gate, ldsp + (16 * m + 4 * v) * kClParStride);
 #pragma unroll
             for (int d = 0; d < D; ++d) z[m][d][int(v)] = zz[d];
+            CM_FENCE();
         });
     });
     stamp(sid + 1);
@@ -302,6 +311,7 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
             nlsum += cm_gp_tail<ALG>(zz, RR, LL, invden, ldsp + (16 * m + 4 * v) * kClParStride);
 #pragma unroll
             for (int d = 0; d < D; ++d) L[m][d][int(v)] = LL[d];
+            CM_FENCE();
         });
     });
     stamp(sid + 3);
@@ -426,10 +436,11 @@ struct CmRaw {
     }
 };
 
-// Rows of a staged tile [16][ROWLEN + 4] -> atomic adds into table rows of ROWLEN floats; lane = column. Adds the rows to
-// table[t_add[row]] (rows sorted by that index: equal consecutive targets are summed first) and, when SUB, subtracts
-// them from table[t_sub[row]] (unsorted). Negative targets are skipped. Lane r (< 16) holds the targets of row r.
-template <int ROWLEN, bool SUB>
+// Rows ROW0 .. ROW0 + NROWS - 1 of the wave's tile, staged as [NROWS][ROWLEN + 4] -> atomic adds into table rows of ROWLEN
+// floats; lane = column. Adds the rows to table[t_add[row]] (rows sorted by that index: equal consecutive targets are
+// summed first) and, when SUB, subtracts them from table[t_sub[row]] (unsorted). Negative targets are skipped. Lane r
+// (< 16) holds the targets of row r.
+template <int ROWLEN, bool SUB, int NROWS = kCmRows, int ROW0 = 0>
 CSMPN_DEV void cm_scatter(const float* sc, int t_add, int t_sub, float* table, int lane) {
     constexpr int SS = ROWLEN + 4, NC = ROWLEN / 64;
     static_assert(ROWLEN % 64 == 0, "whole columns");
@@ -443,13 +454,13 @@ CSMPN_DEV void cm_scatter(const float* sc, int t_add, int t_sub, float* table, i
             if (target == -12345) atomicAdd(table + (size_t)target * ROWLEN + colx, a);
 #endif
         };
-        float val[kCmRows];
+        float val[NROWS];
 #pragma unroll
-        for (int i = 0; i < kCmRows; ++i) val[i] = col[i * SS];
+        for (int i = 0; i < NROWS; ++i) val[i] = col[i * SS];
         float acc = 0.f;
-        int cur = __builtin_amdgcn_readlane(t_add, 0);
-        static_for<0, kCmRows>([&](auto rr) {
-            const int t = __builtin_amdgcn_readlane(t_add, rr);
+        int cur = __builtin_amdgcn_readlane(t_add, ROW0);
+        static_for<0, NROWS>([&](auto rr) {
+            const int t = __builtin_amdgcn_readlane(t_add, ROW0 + rr);
             if (t != cur) {
                 flush(cur, acc);
                 cur = t;
@@ -459,7 +470,7 @@ CSMPN_DEV void cm_scatter(const float* sc, int t_add, int t_sub, float* table, i
         });
         flush(cur, acc);
         if constexpr (SUB) {
-            static_for<0, kCmRows>([&](auto rr) { flush(__builtin_amdgcn_readlane(t_sub, rr), -val[rr]); });
+            static_for<0, NROWS>([&](auto rr) { flush(__builtin_amdgcn_readlane(t_sub, ROW0 + rr), -val[rr]); });
         }
     });
 }
@@ -467,7 +478,7 @@ CSMPN_DEV void cm_scatter(const float* sc, int t_add, int t_sub, float* table, i
 // ---------------------------------------------------------------------------------
 // forward kernel: NBLK blocks (1 or 2), all C channels wide. Tile t (16 rows) belongs to wave t mod (4 gridDim).
 template <class ALG, int C, int MODE, int NBLK, int NA>
-__global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * kCmWaves, CM_FWD_OCC) cemlp_cm_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
@@ -483,7 +494,7 @@ __global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const De
     float* lds = smem;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
-    float* sc = lds + tab_floats + wave * (kCmRows * SS);   // scatter staging tile (edge program)
+    float* sc = lds + tab_floats + wave * (kCmFwdStageRows * SS);   // scatter staging tile (edge program)
     const float* ldsa0 = lds + 4 * lane;
     const float* ldsp0 = lds + T0::par + kClParStride * q;
     const float* ldsa1 = ldsa0 + T0::total;
@@ -523,6 +534,15 @@ __global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const De
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int d = 0; d < D; ++d) in1[m][d] = out[m][d];
+            // the block-1 input rows leave right away (they are far in front of the next tile's loads by then)
+#ifdef CM_X_NOSAVE   // timing experiment only (results wrong): block-1 inputs not saved
+            if (io.save && T.row == -12345) {
+#else
+            if (io.save && T.valid) {
+#endif
+#pragma unroll
+                for (int m = 0; m < MB; ++m) cm_store_piece(io.save + (size_t)T.row * ROW + (16 * m + q) * D, in1[m]);
+            }
             cm_block_forward<ALG, C, T1>(ldsa1, ldsp1, in1, out, stamp, 8);
         }
         // next tile's rows, then this tile's stores (edge program: loads queued behind atomics wait for them; the node
@@ -531,16 +551,6 @@ __global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const De
         T = Tn;
         if constexpr (MODE == MODE_EDGE) raw.issue(io, T, q);
         Tn.template load<NA>(io, tile + 2 * tstride, r);
-        if constexpr (NBLK > 1) {
-#ifdef CM_X_NOSAVE   // timing experiment only (results wrong): block-1 inputs not saved
-            if (io.save && Tc.row == -12345) {
-#else
-            if (io.save && Tc.valid) {
-#endif
-#pragma unroll
-                for (int m = 0; m < MB; ++m) cm_store_piece(io.save + (size_t)Tc.row * ROW + (16 * m + q) * D, in1[m]);
-            }
-        }
         if constexpr (MODE == MODE_EDGE) {
             if (io.row_store) {
                 if (Tc.valid) {
@@ -548,9 +558,17 @@ __global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const De
                     for (int m = 0; m < MB; ++m) cm_store_piece(io.agg + (size_t)Tc.lrow * ROW + (16 * m + q) * D, out[m]);
                 }
             } else {
+                // two halves of 8 rows through one 8-row staging tile (LDS for three workgroups per CU)
+                const int tgt = Tc.valid ? Tc.i_dst : -1;
+                static_for<0, 2>([&](auto hf) {
+                    CM_LDS_ORDER();
+                    if ((r >> 3) == hf) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) cm_store_piece(sc + r * SS + (16 * m + q) * D, out[m]);
-                cm_scatter<ROW, false>(sc, Tc.valid ? Tc.i_dst : -1, -1, io.agg, lane);
+                        for (int m = 0; m < MB; ++m) cm_store_piece(sc + (r & 7) * SS + (16 * m + q) * D, out[m]);
+                    }
+                    CM_LDS_ORDER();
+                    cm_scatter<ROW, false, 8, 8 * hf>(sc, tgt, -1, io.agg, lane);
+                });
             }
         } else if (Tc.valid) {
 #pragma unroll
@@ -574,7 +592,7 @@ __global__ void __launch_bounds__(64 * kCmWaves, 2) cemlp_cm_fwd_kernel(const De
 template <class ALG, int C, int MODE, int NBLK, int NA>
 constexpr size_t cm_fwd_lds_bytes() {
     return sizeof(float) * (CmTab<C, MODE, NA, 0>::total + (NBLK > 1 ? CmTab<C, MODE, NA, 1>::total : 0) +
-                            (MODE == MODE_EDGE ? kCmWaves * kCmRows * (C * ALG::D + 4) : 0));
+                            (MODE == MODE_EDGE ? kCmWaves * kCmFwdStageRows * (C * ALG::D + 4) : 0));
 }
 
 // =================================================================================
@@ -924,8 +942,10 @@ __device__ void cm_bwd_block(const RowIO& io, float* tab, float* work, ClStamp& 
                 CM_FENCE();
             });
             static_for<0, 2>([&](auto half) {
+                CM_LDS_ORDER();
                 cm_tr_write(sc, ggp, half, lane);
                 cm_tr_write(sc + 1024, z, half, lane);
+                CM_LDS_ORDER();
                 cm_wgrad_half<ALG, half>(A.wl, sc, sc + 1024, lane);
             });
         }
@@ -964,8 +984,10 @@ __device__ void cm_bwd_block(const RowIO& io, float* tab, float* work, ClStamp& 
                 CM_FENCE();
             });
             static_for<0, 2>([&](auto half) {
+                CM_LDS_ORDER();
                 cm_tr_write(sc, R, half, lane);
                 cm_tr_write(sc + 1024, z, half, lane);
+                CM_LDS_ORDER();
                 cm_wgrad_half<ALG, half>(A.wr, sc, sc + 1024, lane);
             });
         }
@@ -996,9 +1018,12 @@ __device__ void cm_bwd_block(const RowIO& io, float* tab, float* work, ClStamp& 
         asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
         load_x();
         static_for<0, 2>([&](auto half) {
+            CM_LDS_ORDER();
             cm_tr_write(sc, gz, half, lane);
             static_for<0, NCH>([&](auto ch) {
+                CM_LDS_ORDER();
                 cm_tr_write(sc + 1024, x[ch], half, lane);
+                CM_LDS_ORDER();
                 cm_wgrad_half<ALG, half>(A.w1[ch], sc, sc + 1024, lane);
             });
         });
@@ -1019,7 +1044,9 @@ __device__ void cm_bwd_block(const RowIO& io, float* tab, float* work, ClStamp& 
                 if (io.row_store) {
                     if (T.valid) cm_store_piece(io.gx[0] + (size_t)T.lrow * ROW + q * D, gx);
                 } else {
+                    CM_LDS_ORDER();
                     cm_store_piece(sc + r * SS + q * D, gx);
+                    CM_LDS_ORDER();
                     cm_scatter<ROW, true>(sc, T.valid ? T.i_dst : -1, T.valid ? T.i_src : -1, io.gx[0], lane);
                 }
             }

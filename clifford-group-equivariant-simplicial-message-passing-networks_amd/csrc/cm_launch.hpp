@@ -5,7 +5,7 @@
 #include "cemlp_device.hpp"
 
 namespace csmpn {
-constexpr int kCmMaxFwdGroups = 512;   // 4-wave workgroups of a forward launch: two per CU
+constexpr int kCmMaxFwdGroups = 768;   // 4-wave workgroups of a forward launch: three per CU
 constexpr int kCmMaxBwdGroups = 256;   // ... of a backward launch (one per CU: 512 registers); one slice of partial sums each
 constexpr int kCmSliceCap = 512;       // slices the partial buffer is laid out for (block 1's start behind kCmSliceCap of block 0: = kClSliceCap)
 #define CSMPN_DECLARE_CM(tag)                                                                                  \
