@@ -39,6 +39,10 @@ constexpr int kClWaves = 4;          // waves per workgroup
 constexpr int kClSliceCap = 512;     // workgroups of a backward launch = slices of partial sums per block
 constexpr int kClParStride = 36;     // floats per channel in the per-channel parameter table
 
+// Compiler barrier between the 16-byte vector stores into a staging tile and the float reads of the same LDS bytes (and
+// the next tile's stores behind them): the two access types carry different alias information - cemlp_cm.hpp met the
+// reordering this allows. Costs no instruction.
+#define CL_LDS_ORDER() asm volatile("" ::: "memory")
 CSMPN_DEV f4 cl_ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 CSMPN_DEV void cl_st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 
@@ -826,7 +830,9 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
             if (io.row_store) {
                 if (Tc.valid) CL_GST8(io.agg + (size_t)Tc.lrow * ROW + c * D, sc + r * SS + c * D, out);
             } else {
+                CL_LDS_ORDER();
                 cl_st8(sc + r * SS + c * D, out);
+                CL_LDS_ORDER();
                 cl_scatter<C, ROW, false>(sc, Tc.valid ? Tc.i_dst : -1, -1, io.agg, lane);
             }
         } else if (Tc.valid) {
@@ -973,7 +979,9 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
                 if (io.row_store) {
                     if (Tc.valid) CL_GST8(io.gx[0] + (size_t)Tc.lrow * ROW + c * D, sc + r * SS + c * D, gx);
                 } else {
+                    CL_LDS_ORDER();
                     cl_st8(sc + r * SS + c * D, gx);
+                    CL_LDS_ORDER();
                     cl_scatter<C, ROW, true>(sc, Tc.valid ? Tc.i_dst : -1, Tc.valid ? Tc.i_src : -1, io.gx[0], lane);
                 }
             }
