@@ -66,8 +66,8 @@ def kernel_of(stage, name):
     argument = backward.) cemlp_rl_kernel<Alg, NOG, MODE, NBLK, I0, BWD>, cemlp_pl_kernel<Alg, MODE, NBLK, I0, BWD>,
     cemlp_kernel<Alg, MODE, ...>, cemlp_ps_kernel<Alg, MODE, BWD>."""
     import re
-    # cemlp_cl_{fwd,bwd}_kernel<Alg, C, MODE, NBLK, NA> (round 3: all blocks of a backward in one launch)
-    m = re.search(r"cemlp_cl_(fwd|bwd)_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+    # cemlp_cl_{fwd,bwd}_kernel / cemlp_cm_{fwd,bwd}_kernel<Alg, C, MODE, NBLK, NA> (round 3: all blocks of a backward in one launch)
+    m = re.search(r"cemlp_c[lm]_(fwd|bwd)_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
         return args[1] == ("1" if stage.startswith("edge") else "2") and (m.group(1) == "bwd") == stage.endswith("bwd")
@@ -382,7 +382,7 @@ def main():
         bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
         traffic = pmc_traffic(dom, args.workload)
         roofline = {
-            "bound": "hbm", "kernel": f"{dom} (cemlp_cl_*_kernel: Cl(3,0) 8 channels; cemlp_rl_kernel: Cl(3,0) 16 channels; cemlp_pl_kernel: Cl(5,0)|Cl(4,1) 8 channels; else cemlp_kernel / cemlp_ps_kernel)",
+            "bound": "hbm", "kernel": f"{dom} (cemlp_cl_*_kernel: Cl(3,0) 8 channels; cemlp_rl_kernel: Cl(3,0) 16 channels (backward; their forward: cemlp_cm_fwd_kernel); cemlp_pl_kernel: Cl(5,0)|Cl(4,1) 8 channels; else cemlp_kernel / cemlp_ps_kernel)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             # `frac` prices the ALGORITHMIC bytes (no reuse assumed for the gathers); the counters see fewer
