@@ -11,6 +11,10 @@ the reference's task models compose them, on the HIP-backed layers of this packa
     MD17SimplicialMPNN   trajectory model: MVLinear featurisation, 5 x EGCL (aggr = sum, learned
                        type attributes), CEMLP + MVLinear head on the vertices, vector blades ->
                        MSE / ADE / FDE (md17_cssmpnn.py:135-176)
+    MotionSimplicialMPNN motion-capture model: 4 x EGCL (Cl(3,0), 16 channels, aggr = mean), MVLinear head, positions
+                       relative to the graph's mean (motion_cssmpnn.py:13-163)
+    NBASimplicialMPNN    NBA trajectory model: Cl(2,0), 40 channels, its own embedding modules, 4 x EGCL (aggr = sum),
+                       ADE / FDE over the players (nba_cssmpnn.py:12-190)
 
 Attribute names follow the reference so that its checkpoints load (`state_dict` keys are the
 contract); the bodies are this package's own. Batches are
@@ -204,3 +208,104 @@ class MD17SimplicialMPNN(nn.Module):
         fde = ((loc_pred[:, -1, :] - tgt[:, -1, :]) ** 2).sum(-1).sqrt().reshape(B, -1).mean(-1)
         loss = sq.reshape(B, -1, 3).sum(-1).mean(-1)
         return loss.mean(), {"loss": loss, "ade_loss": ade, "fde_loss": fde}
+
+
+class MotionSimplicialMPNN(nn.Module):
+    """The motion-capture task model (csmpn/models/motion_cssmpnn.py:13-163): Cl(3,0), 16 hidden channels, 4 shared EGCL
+    layers (aggr = mean) - S2's layer shape, served by the channel-MFMA / row-per-lane kernels. batch: pos, vel [S, 3]
+    (vertex rows filled), y [V, 3]. Same parameter names as the reference (feature_embedding exists there and is unused)."""
+
+    def __init__(self, max_dim: int = 2, num_input: int = 2, num_hidden: int = 16, num_out: int = 1, num_layers: int = 4,
+                 condition=True):
+        super().__init__()
+        self.algebra = CliffordAlgebra((1.0, 1.0, 1.0))
+        self.max_dim = max_dim
+        self.num_hidden = num_hidden
+        self.num_node_type = max_dim + 1 if condition else 0
+        self.feature_embedding = MVLinear(self.algebra, num_input + self.num_node_type, num_hidden, subspaces=False)
+        emb = SimplexEmbedding(self.algebra, num_input, num_hidden, max_dim)
+        self.cl_feature_embedding = emb.cl_feature_embedding
+        object.__setattr__(self, "_embed", emb)
+        self.sim_type_embedding = nn.Embedding(num_embeddings=max_dim + 1, embedding_dim=max_dim + 1)
+        self.layers = nn.ModuleList([
+            EGCL(self.algebra, num_hidden, num_hidden, num_hidden, edge_attr_features=2 * self.num_node_type,
+                 node_attr_features=self.num_node_type, aggr="mean", normalization_init=0)
+            for _ in range(num_layers)])
+        self.projection = nn.Sequential(MVLinear(self.algebra, num_hidden, num_out))
+
+    def forward(self, batch, step=0, mode="train"):
+        B = batch.num_graphs
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        node_pos = batch.pos.index_select(0, vr)
+        # positions relative to the mean vertex position of their graph (motion_cssmpnn.py:139-144)
+        mean = segment_mean(node_pos, plan["graph_of_vertex"], B)
+        pos = batch.pos.index_copy(0, vr, node_pos - mean[plan["graph_of_vertex"]])
+        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        x = self._embed(batch, [(pos.unsqueeze(1), 1), (batch.vel.unsqueeze(1), 1)])
+        for layer in self.layers:
+            x = layer(x, batch.edge_index, edge_attr, node_attr)
+        pred = node_pos + self.projection(x.index_select(0, vr))[..., 0, 1:4]
+        loss = ((pred - batch.y.reshape(-1, 3)) ** 2).mean(dim=1)
+        return loss.mean(), {"loss": loss}
+
+
+class NBASimplicialMPNN(nn.Module):
+    """The NBA trajectory task model (csmpn/models/nba_cssmpnn.py:12-190): Cl(2,0), 40 hidden channels, 4 shared EGCL layers
+    (aggr = sum; general row-tile kernels). batch: pos, vel [S, F, 2] (vertex rows filled; num_input = 2 F channels per
+    vertex), y [B * (agents - 1), num_out, 2]; every graph has `agents` vertices, the last one (the ball) is not scored."""
+
+    def __init__(self, max_dim: int = 2, num_input: int = 20, num_hidden: int = 40, num_out: int = 40, num_layers: int = 4,
+                 condition=True, agents: int = 6):
+        super().__init__()
+        self.algebra = CliffordAlgebra((1.0, 1.0))
+        self.max_dim, self.num_input, self.num_hidden, self.num_out, self.agents = max_dim, num_input, num_hidden, num_out, agents
+        self.num_node_type = max_dim + 1 if condition else 0
+        self.feature_embedding = MVLinear(self.algebra, num_input + self.num_node_type, num_hidden, subspaces=False)
+        A = self.algebra
+        self.cl_feature_embedding = nn.Sequential(
+            MVLinear(A, num_input, num_input, subspaces=False),
+            CEMLP(A, 2 * num_input, num_hidden, num_input, n_layers=1, normalization_init=0),
+            nn.Sequential(CEMLP(A, 3 * num_input, num_hidden, num_hidden, n_layers=1, normalization_init=0),
+                          CEMLP(A, num_hidden, num_hidden, num_input, n_layers=1, normalization_init=0)))
+        self.sim_type_embedding = nn.Embedding(num_embeddings=max_dim + 1, embedding_dim=max_dim + 1)
+        self.layers = nn.ModuleList([
+            EGCL(A, num_hidden, num_hidden, num_hidden, edge_attr_features=2 * self.num_node_type,
+                 node_attr_features=self.num_node_type, aggr="sum", normalization_init=0)
+            for _ in range(num_layers)])
+        self.projection = MVLinear(A, num_hidden, num_out)
+
+    def embed(self, batch, pos, vel):
+        """nba_cssmpnn.py:125-158: per dimension, every vertex order of a simplex -> [pos of its vertices | vel of its
+        vertices] as grade-1 channels -> the dimension's module -> sum over the orders."""
+        plan = batch.plan(self.max_dim)
+        out = torch.zeros(batch.x_ind.shape[0], self.num_input, 2 ** self.algebra.dim, device=pos.device, dtype=pos.dtype)
+        for d in range(self.max_dim + 1):
+            rows, pv, nperm = plan["rows"][d], plan["verts"][d], plan["nperm"][d]
+            if rows.shape[0] == 0:
+                continue
+            feats = []
+            for t in (pos, vel):
+                g = t[pv]                                                # [rows * nperm, d + 1, F, 2]
+                feats.append(self.algebra.embed_grade(g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2]), 1))
+            e = self.cl_feature_embedding[d](torch.cat(feats, dim=1).contiguous())
+            out = out.index_copy(0, rows, e.reshape(rows.shape[0], nperm, self.num_input, -1).sum(dim=1))
+        return out
+
+    def forward(self, batch, step=0, mode="train"):
+        B = batch.num_graphs
+        F_ = batch.pos.shape[1]
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        x = self.embed(batch, batch.pos, batch.vel)
+        x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
+        for layer in self.layers:
+            x = layer(x, batch.edge_index, edge_attr, node_attr)
+        pred = self.projection(x.index_select(0, vr))[..., 1:3]                      # [V, num_out, 2]
+        loc_pred = pred.reshape(B, self.agents, self.num_out, -1)[:, :-1].reshape(-1, self.num_out, 2)
+        tgt = batch.y
+        d2 = ((loc_pred.reshape(-1, 2) - tgt.reshape(-1, 2)) ** 2).sum(-1)
+        ade = d2.sqrt().reshape(B, -1, F_).mean(-1).mean(-1)
+        fde = ((loc_pred[:, -1, :] - tgt[:, -1, :]) ** 2).sum(-1).sqrt().reshape(B, -1).mean(-1)
+        return ade.mean(), {"loss": ade, "ade_loss": ade, "fde_loss": fde}

@@ -14,6 +14,8 @@ gradient's dot product with a seeded Gaussian direction (both runs) plus, for pa
   traj_hulls.npz    the 20-step Adam (lr 1e-3) loss trajectory of the hulls model (starting from
                     model_hulls.npz's parameters) over two alternating 4-graph batches (the "matching reference MSE" proxy: the real
                     dataset needs gudhi / DATAROOT).
+  model_motion.npz, model_nba.npz  (`make_model_golden.py motion nba`, round 3) the motion-capture and NBA task models
+                    (motion_cssmpnn.py, nba_cssmpnn.py) in the same form as the two above.
   stages_hulls.npz  (`make_model_golden.py stages`, round 3) embedding output and x behind every EGCL layer of the
                     hulls model on model_hulls.npz's parameters and batch.
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
@@ -43,6 +45,8 @@ sys.path.insert(0, REF)
 
 from csmpn.models.hulls_cssmpnn import HullsCliffordSharedSimplicialMPNN  # noqa: E402
 from csmpn.models.md17_cssmpnn import CliffordSharedSimplicialMPNN_md17  # noqa: E402
+from csmpn.models.motion_cssmpnn import MotionCliffordSharedSimplicialMPNN  # noqa: E402
+from csmpn.models.nba_cssmpnn import NBACliffordSharedSimplicialMPNN  # noqa: E402
 
 spec = importlib.util.spec_from_file_location(
     "_complexes", os.path.join(ROOT, "clifford-group-equivariant-simplicial-message-passing-networks_amd", "csmpn", "data",
@@ -138,6 +142,48 @@ def md17_batch(seed, n_graphs=4, V=5, F=10):
     return b
 
 
+def motion_batch(seed, n_graphs=3, V=7):
+    """Rips complexes over V joints in R^3 (every graph the same V: motion_cssmpnn.py:140 reshapes by it); pos / vel [S, 3] with
+    the vertex rows filled, y [V, 3] per graph."""
+    rng = np.random.default_rng(seed)
+    graphs, ys = [], []
+    for _ in range(n_graphs):
+        base = rng.standard_normal((V, 3)).astype(np.float32)
+        c = cx.rips_complex(base, dis=1.9, max_dim=2)
+        S = c.n_simplices
+        pos, vel = torch.zeros(S, 3), torch.zeros(S, 3)
+        pos[:V] = torch.from_numpy(base)
+        vel[:V] = 0.2 * torch.from_numpy(rng.standard_normal((V, 3)).astype(np.float32))
+        c.features.update(pos=pos, vel=vel)
+        graphs.append(c)
+        ys.append(pos[:V] + 0.1 * torch.from_numpy(rng.standard_normal((V, 3)).astype(np.float32)))
+    b = cx.collate(graphs)
+    b.y = torch.cat(ys, dim=0)
+    b._names.append("y")
+    return b
+
+
+def nba_batch(seed, n_graphs=3, V=6, F=10):
+    """Rips complexes over 6 agents in the plane (5 players + the ball, nba_cssmpnn.py:176); pos / vel [S, F, 2] with the
+    vertex rows filled, y [5, 4 F, 2] per graph."""
+    rng = np.random.default_rng(seed)
+    graphs, ys = [], []
+    for _ in range(n_graphs):
+        base = rng.standard_normal((V, 2)).astype(np.float32)
+        c = cx.rips_complex(base, dis=1.6, max_dim=2)
+        S = c.n_simplices
+        pos, vel = torch.zeros(S, F, 2), torch.zeros(S, F, 2)
+        pos[:V] = torch.from_numpy(base)[:, None, :] + 0.05 * torch.from_numpy(rng.standard_normal((V, F, 2)).astype(np.float32))
+        vel[:V] = 0.1 * torch.from_numpy(rng.standard_normal((V, F, 2)).astype(np.float32))
+        c.features.update(pos=pos, vel=vel)
+        graphs.append(c)
+        ys.append(torch.from_numpy(rng.standard_normal((V - 1, 4 * F, 2)).astype(np.float32)))
+    b = cx.collate(graphs)
+    b.y = torch.cat(ys, dim=0)
+    b._names.append("y")
+    return b
+
+
 def save_batch(out, batch, prefix="b/"):
     for k in batch._names:
         out[prefix + k] = npy(getattr(batch, k))
@@ -185,6 +231,32 @@ def make_md17():
     record_model(out, model, CliffordSharedSimplicialMPNN_md17, batch)
     np.savez_compressed(os.path.join(HERE, "model_md17.npz"), **out)
     print("md17 model: loss", out["f32/backprop_loss"], out["f64/backprop_loss"])
+
+
+def make_motion():
+    """Round 3: model_motion.npz - MotionCliffordSharedSimplicialMPNN (Cl(3,0), 16 channels, 4 layers, aggr = mean,
+    motion_cssmpnn.py:13-163) on a 3-graph batch of 7-joint Rips complexes."""
+    out = {}
+    torch.manual_seed(303)
+    model = MotionCliffordSharedSimplicialMPNN()
+    batch = motion_batch(11)
+    save_batch(out, batch)
+    record_model(out, model, MotionCliffordSharedSimplicialMPNN, batch)
+    np.savez_compressed(os.path.join(HERE, "model_motion.npz"), **out)
+    print("motion model: loss", out["f32/backprop_loss"], out["f64/backprop_loss"])
+
+
+def make_nba():
+    """Round 3: model_nba.npz - NBACliffordSharedSimplicialMPNN (Cl(2,0), 40 channels, 4 layers, aggr = sum,
+    nba_cssmpnn.py:12-190) on a 3-graph batch of 6-agent Rips complexes."""
+    out = {}
+    torch.manual_seed(404)
+    model = NBACliffordSharedSimplicialMPNN()
+    batch = nba_batch(13)
+    save_batch(out, batch)
+    record_model(out, model, NBACliffordSharedSimplicialMPNN, batch)
+    np.savez_compressed(os.path.join(HERE, "model_nba.npz"), **out)
+    print("nba model: loss", out["f32/backprop_loss"], out["f64/backprop_loss"])
 
 
 def make_hulls_stages():
@@ -238,6 +310,10 @@ if __name__ == "__main__":
         make_hulls_stages()
         sys.exit(0)
     which = sys.argv[1:] or ["md17", "hulls"]
+    if "motion" in which:
+        make_motion()
+    if "nba" in which:
+        make_nba()
     if "md17" in which:
         make_md17()
     if "hulls" in which:
