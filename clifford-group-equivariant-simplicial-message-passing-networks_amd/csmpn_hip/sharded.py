@@ -815,3 +815,117 @@ class GraphedDstStep:
             torch.add(self.gh_rs[:n], self.gh_node, out=self.gh_loc)
         else:
             torch.add(self.gh_edge[self.plan.lo:self.plan.hi], self.gh_node, out=self.gh_loc)
+
+
+class GraphedDstStackStep:
+    """Forward + backward of L chained destination-partitioned layers on fixed buffers, h resident:
+    2 L HIP graphs with one collective between consecutive graphs and nothing else on the host -
+      forward  k = 0 .. L-1:  [rows of layer k's input back from the padded layout (k > 0), edge forward on the owned
+                               edges, node forward on the owned slice, slice padded]  -> all-gather
+      backward k = L-1 .. 0:  [d/d(output slice) = reduce-scattered rows + the node stage's d/dh of layer k + 1, node
+                               backward, edge backward, d/dh rows to the padded layout] -> reduce-scatter
+    and ONE all-reduce of the parameter gradients of all layers at the end. `out` = the replicated output of the last
+    layer, `gh_loc` = this rank's slice of d/dh, `flat` = the parameter gradients (layer by layer, edge model then
+    node model, in flat_params() order). World size 1: the collectives are copies."""
+
+    def __init__(self, stack: "DstPartitionedStack", plan: DstPlan, h, edge_attr_local, node_attr, gout):
+        be, self.group, self.plan = stack.backend, stack.group, plan
+        layers = list(stack.layers)
+        self.L = L = len(layers)
+        specs = [l.spec() for l in layers]
+        pes = [l.edge_model.flat_params() for l in layers]
+        pns = [l.node_model.flat_params() for l in layers]
+        lo, hi = plan.lo, plan.hi
+        n = hi - lo
+        self._multi = plan.world > 1
+        h0 = h.detach().contiguous()
+        na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
+        deg_loc = plan.deg[lo:hi].contiguous()
+        gout_loc = gout[lo:hi].contiguous()
+        row = tuple(h0.shape[1:])
+        self.out_all = [h0.new_empty((plan.world * plan.per,) + row) for _ in range(L)]   # all-gather targets
+        self.gh_rs = [h0.new_empty((plan.per,) + row) for _ in range(L)]                  # reduce-scatter targets
+
+        def fwd(k):
+            x = h0 if k == 0 else plan.from_padded(self.out_all[k - 1])
+            agg, st_e = be.edge_forward(specs[k], plan.csr, x, edge_attr_local, pes[k])
+            out_loc, st_n = be.node_forward(specs[k], deg_loc, x[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pns[k])
+            return x, agg, st_e, st_n, plan.pad_slice(out_loc)
+
+        def bwd(k, x, agg, st_e, st_n, gh_node_next):
+            g_loc = gout_loc if k == L - 1 else self.gh_rs[k + 1][:n] + gh_node_next
+            gh_node, g_agg_loc, _g, views_n = be.node_backward(specs[k], deg_loc, x[lo:hi].contiguous(), agg[lo:hi].contiguous(),
+                                                               na_loc, pns[k], g_loc, False, st_n)
+            g_agg = torch.zeros_like(agg)
+            g_agg[lo:hi] = g_agg_loc
+            gh_edge = torch.zeros_like(x)
+            _g_ea, views_e = be.edge_backward(specs[k], plan.csr, x, edge_attr_local, pes[k], g_agg, gh_edge, False, st_e)
+            flat = torch.cat([v.reshape(-1) for v in list(views_e) + list(views_n) if v is not None])
+            return gh_node, plan.to_padded(gh_edge), flat
+
+        def gather(k, pad):
+            if self._multi:
+                _all_gather_rows(self.out_all[k], pad, self.group)
+            else:
+                self.out_all[k].copy_(pad)
+
+        def scatter(k, pad):
+            if self._multi:
+                _reduce_scatter_rows(self.gh_rs[k], pad, self.group)
+            else:
+                self.gh_rs[k].copy_(pad)
+        self._gather, self._scatter = gather, scatter
+
+        # warm-up on a side stream (allocations, lazy kernel loads), then one capture per segment
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = []
+            for k in range(L):
+                st.append(fwd(k))
+                gather(k, st[k][4])
+            ghn = None
+            for k in range(L - 1, -1, -1):
+                ghn, pad, _f = bwd(k, *st[k][:4], ghn)
+                scatter(k, pad)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.gf, self.gb = [], [None] * L
+        self._st, self._bw = [], [None] * L
+        pool = None
+        for k in range(L):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                self._st.append(fwd(k))
+            pool = pool or g.pool()
+            self.gf.append(g)
+            gather(k, self._st[k][4])      # the next segment's capture reads a buffer of the right content
+        ghn = None
+        for k in range(L - 1, -1, -1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                self._bw[k] = bwd(k, *self._st[k][:4], ghn)
+            self.gb[k] = g
+            ghn = self._bw[k][0]
+            scatter(k, self._bw[k][1])
+        self.flat = torch.cat([self._bw[k][2] for k in range(L)])
+        self.gh_loc = torch.empty_like(self._bw[0][0])
+        self.out = None
+        self.bytes_per_step = 0
+        if self._multi:
+            w = plan.world
+            self.bytes_per_step = int(L * 2 * w * plan.per * h0[0].numel() * 4 * (w - 1) / w + 2 * self.flat.numel() * 4 * (w - 1) / w)
+
+    def run(self):
+        L, n = self.L, self.plan.hi - self.plan.lo
+        for k in range(L):
+            self.gf[k].replay()
+            self._gather(k, self._st[k][4])
+        for k in range(L - 1, -1, -1):
+            self.gb[k].replay()
+            self._scatter(k, self._bw[k][1])
+        torch.add(self.gh_rs[0][:n], self._bw[0][0], out=self.gh_loc)
+        torch.cat([self._bw[k][2] for k in range(L)], out=self.flat)
+        if self._multi:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.out = self.plan.from_padded(self.out_all[L - 1])

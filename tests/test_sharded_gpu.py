@@ -207,6 +207,89 @@ def test_dst_partitioned_stack_overlap_hip():
             assert v < 5e-5, (rank, k, v)
 
 
+def _worker_graphed_stack(rank, world, port, q):
+    """GraphedDstStackStep (2 L graph segments + collectives) against the autograd chain of the same stack."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        from csmpn_hip import sharded
+        from oracle import ref_path as O
+        dev = torch.device("cuda:0")
+        torch.manual_seed(0)
+        metric, C = (1.0, 1.0, 1.0), 8
+        alg = pkg.CliffordAlgebra(metric)
+        layers = [pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr=a).to(dev) for a in ("mean", "sum", "mean")]
+        N, E = 403, 5003
+        h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=5))
+        gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(6)).to(dev)
+        stack = sharded.DstPartitionedStack(layers)
+        plan = stack.plan(ei, N)
+        eal = ea[plan.edge_ids].contiguous()
+        hh = h.clone().requires_grad_(True)
+        y = stack(hh, plan, eal, na)
+        params = [p for l in layers for p in l.edge_model.flat_params() + l.node_model.flat_params() if p is not None]
+        gs = torch.autograd.grad(y, [hh] + params, gout)
+        step = sharded.GraphedDstStackStep(stack, plan, h, eal, na, gout)
+        for _ in range(2):
+            step.run()
+        torch.cuda.synchronize()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        lo, hi = plan.lo, plan.hi
+        flat_ref = torch.cat([g.reshape(-1) for g in gs[1:]])
+        res = {"y": rel(step.out, y.detach()), "gh": rel(step.gh_loc, gs[0][lo:hi]), "params": rel(step.flat, flat_ref),
+               "n_flat": float(step.flat.numel() != flat_ref.numel())}
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_graphed_dst_stack_step_matches_autograd():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_graphed_stack, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, res in results:
+        for k, v in res.items():
+            assert v < 5e-5, (rank, k, v)
+
+
+def test_graphed_dst_stack_step_single_process():
+    """World size 1 (no process group): the collectives of GraphedDstStackStep are copies; same check as above."""
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module(PKG)
+    from csmpn_hip import sharded
+    from oracle import ref_path as O
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    metric, C = (1.0, 1.0, 1.0), 16
+    alg = pkg.CliffordAlgebra(metric)
+    layers = [pkg.EGCL(alg, C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev) for _ in range(2)]
+    N, E = 300, 4001
+    h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=7))
+    gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(8)).to(dev)
+    stack = sharded.DstPartitionedStack(layers)
+    plan = stack.plan(ei, N)
+    hh = h.clone().requires_grad_(True)
+    y = stack(hh, plan, ea, na)
+    params = [p for l in layers for p in l.edge_model.flat_params() + l.node_model.flat_params() if p is not None]
+    gs = torch.autograd.grad(y, [hh] + params, gout)
+    step = sharded.GraphedDstStackStep(stack, plan, h, ea, na, gout)
+    for _ in range(2):
+        step.run()
+    torch.cuda.synchronize()
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+    assert rel(step.out, y.detach()) < 2e-5 and rel(step.gh_loc, gs[0]) < 5e-5
+    assert rel(step.flat, torch.cat([g.reshape(-1) for g in gs[1:]])) < 5e-5
+
+
 # ----------------------------------------------------------------------------- data parallel over graphs
 
 def _worker_ddp(rank, world, port, q):
