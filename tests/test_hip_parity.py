@@ -409,6 +409,44 @@ def test_channel_mfma_backward_opt_in(pkg):
     assert " passed" in log and "failed" not in log, tail
 
 
+_CM_BWD_SCRIPT = r"""
+import importlib, os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+pkg = importlib.import_module("clifford-group-equivariant-simplicial-message-passing-networks_amd")
+from oracle import ref_path as O
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+metric, C, N, E = (1.0, 1.0, 1.0), 16, 3000, 40000
+layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
+h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=3))
+gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+hh = h.clone().requires_grad_(True)
+gs = torch.autograd.grad(layer(hh, ei, ea, na), [hh] + list(layer.parameters()), gout)
+torch.cuda.synchronize()
+torch.save([g.cpu() for g in gs], sys.argv[2])
+"""
+
+
+def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path):
+    """The opt-in channel-MFMA backward where every wave walks several row tiles (40 000 edges = 2 500 tiles on 1 024
+    waves; 3 000 nodes): d/dh and every parameter gradient against the default path (row-per-lane backward) of the same
+    layer, each in its own process (the switch is read once per process)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, extra in (("rl", {}), ("cm", {"CSMPN_CM_BWD": "1", "CSMPN_DEBUG": "1"})):
+        f = str(tmp_path / f"g_{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", _CM_BWD_SCRIPT, root, f], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        if tag == "cm":
+            assert "cm mode=1 bwd=1" in r.stderr and "cm mode=2 bwd=1" in r.stderr, r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    for i, (a, b) in enumerate(zip(outs["cm"], outs["rl"])):
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        assert err < 2e-5, (i, err)
+
+
 def test_wide_kernels_reproducible_for_fixed_inputs(pkg):
     """The wide parity-lane node / edge stages on fixed inputs: outputs, every data gradient and the dense weight
     gradients (per-workgroup slices + fixed-order reduction) are bit-identical from run to run - no race between the
