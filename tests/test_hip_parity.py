@@ -604,6 +604,44 @@ def test_edge_stage_additivity_full_size(pkg, metric, C, N, E):
         assert relmax((x + y).cpu().numpy(), f.cpu().numpy()) < tol, f"tensor {i}"
 
 
+@pytest.mark.parametrize("metric,C,N", [((1.0, 1.0, 1.0), 8, 50_000), ((1.0, 1.0, 1.0), 16, 100_000)])
+def test_node_stage_row_partition_full_size(pkg, metric, C, N):
+    """The node stage is row-wise: at sizes where every wave of the node kernels walks several row tiles (the oracle
+    cannot reach them) the outputs and d/dh, d/d(agg) rows of a row subset equal those rows of the full launch, and the
+    node model's parameter gradients add up over a partition of the rows."""
+    from csmpn_hip import ops
+    D = 1 << len(metric)
+    torch.manual_seed(0)
+    layer = pkg.EGCL(pkg.CliffordAlgebra(tuple(metric)), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
+    g = torch.Generator(device=dev()).manual_seed(2)
+    h = torch.randn(N, C, D, device=dev(), generator=g)
+    agg = torch.randn(N, C, D, device=dev(), generator=g)
+    na = torch.zeros(N, 3, D, device=dev())
+    na[torch.arange(N, device=dev()), torch.arange(N, device=dev()) % 3, 0] = 1.0
+    deg = (torch.arange(N, device=dev()) % 7).to(torch.int32)
+    gout = torch.randn(N, C, D, device=dev(), generator=g)
+    be, spec = ops.HipBackend, layer.spec()
+    pn = layer.node_model.flat_params()
+
+    def run(lo, hi):
+        sl = slice(lo, hi)
+        args = (deg[sl].contiguous(), h[sl].contiguous(), agg[sl].contiguous(), na[sl].contiguous())
+        out, st = be.node_forward(spec, *args, pn)
+        gh, g_agg, _g, views = be.node_backward(spec, *args, pn, gout[sl].contiguous(), False, st)
+        torch.cuda.synchronize()
+        return out, gh, g_agg, [v.clone() for v in views if v is not None]
+
+    cut = N // 3 + 5
+    full, a, b = run(0, N), run(0, cut), run(cut, N)
+    for i in range(3):
+        ref = full[i]
+        got = torch.cat([a[i], b[i]], dim=0)
+        assert torch.isfinite(ref).all()
+        assert relmax(got.cpu().numpy(), ref.cpu().numpy()) < 1e-5, f"row tensor {i}"
+    for i, (f, x, y) in enumerate(zip(full[3], a[3], b[3])):
+        assert relmax((x + y).cpu().numpy(), f.cpu().numpy()) < 1e-4, f"parameter gradient {i}"
+
+
 @pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0, 1.0, 1.0), 12), ((1.0, 1.0, 1.0, 1.0, -1.0), 8),
                                       ((1.0,) * 5, 28)])
 def test_saturated_gates_stay_finite(pkg, metric, C):
