@@ -44,6 +44,8 @@ WORKLOADS = {
     "S3": ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000),
     # not a BASELINE throughput config: one layer of the convex-hulls width (Cl(5,0), 28 channels) at S1's size
     "H28": ((1.0, 1.0, 1.0, 1.0, 1.0), 28, 10_000, 100_000),
+    # not a BASELINE config: the two-wave variant of the wide parity-lane kernels (Cl(5,0), 16 channels) at S1's size
+    "H16": ((1.0, 1.0, 1.0, 1.0, 1.0), 16, 10_000, 100_000),
     # BASELINE config 3's layer shape (md17_cssmpnn.py: Cl(3,0), 32 channels, aggr = sum) at S1's size
     "M32": ((1.0, 1.0, 1.0), 32, 10_000, 100_000),
 }

@@ -32,6 +32,10 @@ struct PlwCfg {
     static constexpr int ROW = C * D;
     static_assert(C > 8 * (NG - 1) && C <= 8 * NG, "NG = ceil(C / 8)");
     static constexpr int WG_PER_CU_BWD = 4 / NG_ > 0 ? 4 / NG_ : 1;   // one wave per SIMD in the backward
+    // HIP's second __launch_bounds__ argument counts WAVES PER SIMD (execution unit), not workgroups per CU: W workgroups of
+    // NG waves per CU are W NG / 4 waves per SIMD. (Rounds 1-2 passed the workgroup count: the one- and two-wave variants were
+    // compiled for 4 / 2 waves per SIMD in the backward - 128 / 256 registers, 0.5-1.3 KB of scratch per lane - instead of one.)
+    static constexpr int waves_per_simd(int wgs_per_cu) { return wgs_per_cu * NG_ / 4 > 0 ? wgs_per_cu * NG_ / 4 : 1; }
     static_assert(NA >= 0 && NA <= 8, "attribute channels fit one chunk");
     static_assert(NBLK == 1 || NBLK == 2, "one or two blocks");
     static_assert(MODE != MODE_PLAIN || NA > 0, "MODE_PLAIN: NA = input channels (one chunk)");
@@ -297,7 +301,9 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
 // ---------------------------------------------------------------------------------
 // forward kernel: two blocks of C channels. BWD kernels: see cemlp_plw_bwd below.
 template <class ALG, class CF>
-__global__ void __launch_bounds__(64 * CF::NG, CF::fwd_total * 4 <= 80 * 1024 ? 2 * CF::WG_PER_CU_BWD : CF::WG_PER_CU_BWD) cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 <= 80 * 1024 ? 2 * CF::WG_PER_CU_BWD : CF::WG_PER_CU_BWD)
+                                                             : CF::waves_per_simd(CF::fwd_total * 4 <= 80 * 1024 ? 2 * CF::WG_PER_CU_BWD : CF::WG_PER_CU_BWD))
+    cemlp_plw_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
@@ -725,7 +731,7 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
 // backward -> input gradients (scatter / rows). Parameter gradients of block BLK.
 template <class ALG, class CF, int BLK>
-__global__ void __launch_bounds__(64 * CF::NG, CF::WG_PER_CU_BWD) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD : CF::waves_per_simd(CF::WG_PER_CU_BWD)) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
