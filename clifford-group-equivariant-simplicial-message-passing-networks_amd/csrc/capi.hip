@@ -359,6 +359,8 @@ int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool b
 
 // bwd / stage_rowlen decide the footprint. stage_rowlen: dense staging row length needed in
 // buf_g (edge forward scatter).
+bool general_phased_shape(int n, const csmpn_block_params* blocks, int nblk);   // below, beside the saved-region size
+
 int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads, int nblk,
               void* workspace, size_t workspace_bytes, bool bwd, int stage_rowlen, bool use_saved, long rows,
               Plan& plan, bool deterministic = false) {
@@ -459,6 +461,35 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
             L = Ls; ch = cs; C.share_inz = 1;
         }
     }
+    // Phased backward (round 3, cemlp_kernel.hpp): block by block, last first, each over all row tiles - the LDS mirror then
+    // holds ONE block's gradient tensors. Taken when that puts more waves on the CU than the all-blocks mirror allows (md17's
+    // 32-channel edge model: 110 KB of mirror left room for one 38 KB row tile = 2 waves per CU; 57 KB leave room for two).
+    // Needs the saved block inputs and the hand-over region behind them (general_phased_shape: the same predicate sizes it).
+    C.phased = 0;
+    int mirror_used = mirror;
+    static const bool no_phased = getenv("CSMPN_NO_PHASED") && atoi(getenv("CSMPN_NO_PHASED"));
+    // Only for launches with many row tiles per workgroup (two passes over the tiles, the hand-over rows and the extra
+    // barriers cost more than the second tile buys on small batches: the md17 task model's 704-tile edge stage ran 6 % slower
+    // phased), and only where the all-blocks form already keeps a mirror (never away from the no-mirror variant).
+    const long phased_min_rows = 16L * 256 * 8;
+    if (bwd && use_saved && nblk > 1 && !ps && H == 1 && !no_phased && rows >= phased_min_rows && ch.var == VAR_GROUP &&
+        general_phased_shape(n, blocks, nblk)) {
+        int mirror_max = 0;
+        for (int k = 0; k < nblk; ++k) {
+            const int m = rup(mirror_floats_of(C.b[k].I, C.b[k].O, G, P, C.b[k].w1_sub), 4);
+            mirror_max = m > mirror_max ? m : mirror_max;
+        }
+        auto resident = [&](const Choice& c) { const int w = c.rt * c.wgs * MT; return w < 4 ? w : 4; };
+        for (int sh = 0; sh < (allow_share ? 2 : 1); ++sh) {
+            const TileLayout Lp = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps, sh != 0);
+            const Choice cp = choose_variant(MT, (size_t)Lp.total * 4, (size_t)mirror_max * 4, (size_t)wstore * 4, bwd, ps);
+            if (cp.var == VAR_GROUP && resident(cp) > resident(ch)) {
+                L = Lp; ch = cp; C.share_inz = sh; C.phased = 1; mirror_used = mirror_max;
+            }
+        }
+        if (C.phased)
+            for (int k = 0; k < nblk; ++k) C.b[k].lds_goff = 0;
+    }
     // Deterministic mode on these kernels (n <= 3: Cl(2,0), Cl(3,0) widths outside the lane kernels - the md17 / NBA layers):
     // ONE row tile per workgroup, so that every gradient word (LDS mirror or the workgroup's global copy) has one writing
     // wave - the MT waves of a tile own disjoint channels - and the order of its sums is the tile order.
@@ -474,7 +505,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     if (H == 2 && ch.var != VAR_WAVE) return fail(CSMPN_ERR_INVALID, "internal: H=2 without the single-wave variant");
     C.RT = ch.rt;
     plan.var = ch.var;
-    C.mirror_floats = ch.mirror ? mirror : 0;
+    C.mirror_floats = ch.mirror ? mirror_used : 0;
     C.wstore_floats = ch.var == VAR_WAVE ? wstore : 0;
     if (ch.var != VAR_GLOBAL) {
         C.gtiles = nullptr;
@@ -580,6 +611,21 @@ bool cl_shape(int n, const csmpn_block_params* blocks, int nblk) {
     if (blocks[1].out_features != ch || blocks[1].in_features != ch) return false;
     if (has_cemlp_cl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_cl_n3(MODE_NODE, nblk, ch, i0)) return true;
     return cm_bwd_enabled() && (has_cemlp_cm_n3(MODE_EDGE, nblk, ch, i0, true) || has_cemlp_cm_n3(MODE_NODE, nblk, ch, i0, true));
+}
+
+// Shapes whose backward may run block by block on the general kernels (cemlp_kernel.hpp, `phased`): small algebras, more
+// than one block, no lane-kernel family of their own. They get a hand-over region as large as the saved inputs behind them.
+bool general_phased_shape(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n > 3 || nblk < 2 || nblk > CSMPN_MAX_BLOCKS) return false;
+    if (n == 3 && nblk == 2) {
+        const int ch = blocks[0].out_features, i0 = blocks[0].in_features;
+        if (blocks[1].out_features == ch && blocks[1].in_features == ch) {
+            if (cl_shape(n, blocks, nblk)) return false;
+            if (has_cemlp_rl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_rl_n3(MODE_NODE, nblk, ch, i0)) return false;
+            if (has_cemlp_cm_n3(MODE_EDGE, nblk, ch, i0, false) || has_cemlp_cm_n3(MODE_NODE, nblk, ch, i0, false)) return false;
+        }
+    }
+    return true;
 }
 
 // bytes of the wide parity-lane kernels' rotation tables (cemlp_plw.hpp), also carved from the END of the workspace
@@ -884,6 +930,12 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             det_slices = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - det_bytes) & ~(size_t)255));
         }
     }
+    if (bwd && plan.C.phased) {   // hand-over region of the phased backward: behind the saved inputs, laid out like them
+        size_t ch_saved = 0;
+        for (int k = 0; k + 1 < plan.C.nblk; ++k) ch_saved += (size_t)plan.C.b[k].O;
+        const int Dn = id == ALG_N2 ? 4 : (id == ALG_N3 ? 8 : 2);
+        io.plw_g1 = const_cast<float*>(io.saved) + ch_saved * (size_t)io.rows * Dn;
+    }
     // general row-tile kernels from here on: they read packed weight fragments (the lane kernels above do not)
     if (need_pack) {
         const int rcp = run_pack(plan, st);
@@ -1118,6 +1170,7 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
     if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
     if (cl_shape(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane backward likewise
+    else if (general_phased_shape(n, blocks, n_blocks)) ch *= 2;               // the general kernels' phased backward: one hand-over slot per saved input
     return ch << n;
 }
 

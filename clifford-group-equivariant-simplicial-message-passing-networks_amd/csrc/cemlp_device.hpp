@@ -78,7 +78,7 @@ struct DevCemlp {
                          // where LDS, not registers, limits the resident waves)
     float* gtiles;       // non-null: row-tile buffers live in this global scratch (too big for LDS)
     int det_slice_floats;  // > 0: deterministic mode of the general kernels - the g* pointers are slice 0 of a per-workgroup region
-    int pad_det_;
+    int phased;            // 1: backward block by block (outer loop over blocks, last first): mirror of ONE block in LDS, d/d(block input) rows through io.plw_g1
     DevBlock b[4];
 };
 

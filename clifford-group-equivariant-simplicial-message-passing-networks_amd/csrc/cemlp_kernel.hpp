@@ -404,6 +404,13 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         return o * (size_t)io.rows * D;
     };
     const bool use_saved = BWD && io.saved != nullptr && C.nblk > 1;
+    // Phased backward (round 3; plan.C.phased, needs the saved block inputs): the blocks one after the other, last first,
+    // each over ALL row tiles of the workgroup - the LDS mirror holds ONE block's gradient tensors (flushed between the
+    // phases), which leaves room for a second row tile per workgroup where both blocks' mirrors did not (md17's 32
+    // channels: 2 instead of 4 waves per CU). A wave keeps its tiles from phase to phase: the rows d/d(block input) it
+    // reads in phase k - 1 are the ones it wrote itself in phase k (io.plw_g1, laid out like the saved inputs).
+    const bool phased = BWD && C.phased != 0 && use_saved;
+  for (int ph = phased ? C.nblk - 1 : 0; ph >= 0; --ph) {
     TileIdx nidx = load_tile_indices<R>(io, ((long)blockIdx.x * RT + rt) * R, tid_rt);
 
     for (long iter = 0; iter < niter; ++iter) {
@@ -413,9 +420,10 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         tile_sync<VAR>();
         // the next tile's indices travel while this tile computes
         nidx = load_tile_indices<R>(io, row0 + tiles_per_iter * R, tid_rt);
-        if (use_saved) {
-            const DevBlock& Bl = C.b[C.nblk - 1];
-            stage_plain<ALG, H>(io.saved + save_off(C.nblk - 1), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
+        if (use_saved && (!phased || ph > 0)) {
+            const int kin = phased ? ph : C.nblk - 1;
+            const DevBlock& Bl = C.b[kin];
+            stage_plain<ALG, H>(io.saved + save_off(kin), Bl.I, io.rows, buf_in, Bl.CPi, row0, tid_rt, nthr_rt);
         } else {
             stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
         }
@@ -494,16 +502,19 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         } else {
             // ------------------------------------------------------------ backward
             const int OL = BL.O;
+            const bool handed = phased && ph + 1 < C.nblk;   // d/d(out of block ph) = the rows phase ph + 1 wrote
+            const int OG = handed ? C.b[ph].O : OL;
+            const float* gsrc = handed ? io.plw_g1 + save_off(ph + 1) : io.gy;
             f4 gout[D];
             {
                 const int c = NW * mt + ge.cn;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const long grow = row0 + ge.r0 + v;
-                    const bool ok = grow < io.rows && c < OL;
+                    const bool ok = grow < io.rows && c < OG;
                     long srow = grow;
-                    if (MODE == MODE_EDGE && ok) srow = tidx[ge.r0 + v];
-                    const float* p = io.gy + (srow * OL + c) * D;
+                    if (MODE == MODE_EDGE && ok && !handed) srow = tidx[ge.r0 + v];
+                    const float* p = gsrc + (srow * OG + c) * D;
 #pragma unroll
                     for (int d4 = 0; d4 < D; d4 += 4) {
                         const f4 val = ok ? *reinterpret_cast<const f4*>(p + d4) : splat(0.f);
@@ -516,10 +527,10 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
             constexpr bool PARK = VAR == VAR_WAVE;
             if constexpr (PARK) park<ALG>(gout, buf_g, lane);
             ge.stamp(1);
-            for (int k = C.nblk - 1; k >= 0; --k) {
+            for (int k = phased ? ph : C.nblk - 1; k >= (phased ? ph : 0); --k) {
                 const DevBlock& B = C.b[k];
                 const float* in = buf_in;
-                if (use_saved && k + 1 < C.nblk) {
+                if (use_saved && k + 1 < C.nblk && !phased) {   // (phased: the tile's staging above brought this block's input)
                     // this block's input replaces the previous one in the single input buffer
                     if (k == 0) stage_input<ALG, H, kModeSegs<MODE>>(io, buf_in, tidx, B0.CPi, row0, tid_rt, nthr_rt);
                     else stage_plain<ALG, H>(io.saved + save_off(k), B.I, io.rows, buf_in, B.CPi, row0, tid_rt, nthr_rt);
@@ -567,7 +578,23 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
                     if (mt < B.NTi)
                         linear_from_tile<ALG, H, WLDS, true>(gout, buf_g, B.CPo, B.KKo, sW1t, mt, ge);
                     tile_sync<VAR>();
-                    if constexpr (PARK) { park<ALG>(gout, buf_g, lane); tile_sync<VAR>(); }
+                    if (phased) {   // the rows go to the hand-over region; this wave reads them back in phase k - 1
+                        const int ci = NW * mt + ge.cn;
+                        if (mt < B.NTi && ci < B.I) {
+                            float* hp = io.plw_g1 + save_off(k);
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const long grow = row0 + ge.r0 + v;
+                                if (grow < io.rows) {
+#pragma unroll
+                                    for (int d4 = 0; d4 < D; d4 += 4)
+                                        *reinterpret_cast<f4*>(hp + (grow * B.I + ci) * D + d4) =
+                                            f4{gout[d4][v], gout[d4 + 1][v], gout[d4 + 2][v], gout[d4 + 3][v]};
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (PARK) { if (!phased) { park<ALG>(gout, buf_g, lane); tile_sync<VAR>(); } }
                     ge.stamp(17);
                 } else {
                     float* stage = buf_in;   // free: block_backward ended with a tile sync
@@ -636,12 +663,27 @@ __global__ void __launch_bounds__(BWD ? 256 : 512) cemlp_kernel(const DevCemlp C
         }
     }
 
+    if (phased) {
+        // end of phase ph: its hand-over rows have left for L2, its gradient sums leave the mirror, which is zeroed for the
+        // next block (all blocks share offset 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (BWD && in_lds) {
+            flush_mirror<ALG>(C.b[ph], mirror, threadIdx.x, blockDim.x, (size_t)blockIdx.x * (size_t)C.det_slice_floats);
+            __syncthreads();
+            for (int e = threadIdx.x; e < C.mirror_floats; e += blockDim.x) smem[e] = 0.f;
+        }
+        __syncthreads();
+    }
+  }   // phases
+
     if constexpr (BWD && in_lds) {
         __syncthreads();
         // deterministic mode: this workgroup's private copy of the accumulators (one row tile per workgroup: every word
         // has one writing wave, in tile order); det_reduce_kernel adds the copies in a fixed order
-        for (int k = 0; k < C.nblk; ++k)
-            flush_mirror<ALG>(C.b[k], mirror, threadIdx.x, blockDim.x, (size_t)blockIdx.x * (size_t)C.det_slice_floats);
+        if (!phased)
+            for (int k = 0; k < C.nblk; ++k)
+                flush_mirror<ALG>(C.b[k], mirror, threadIdx.x, blockDim.x, (size_t)blockIdx.x * (size_t)C.det_slice_floats);
     }
 #ifdef CSMPN_STAMPS
     ge.stamp(19);
