@@ -129,10 +129,11 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
  * n_nodes of the call, in the kernel's own row order) into save_inputs when it is non-NULL, and
  * the backward reads them from saved_inputs instead of recomputing the earlier blocks (one
  * block forward less per row, and a smaller LDS footprint). NULL on either side = recompute.
- * Floats per row: csmpn_cemlp_saved_floats_per_row(); for two-block Cl(5,0) CEMLPs of 9 .. 32 channels and for the
- * two-block 8-channel Cl(3,0) EGCL shapes (edge model 14 -> 8 -> 8, node model 19 -> 8 -> 8) this includes
- * one more [rows, O, D] region behind the saved inputs that the backward uses as scratch (its block-1 launch hands
- * d/d(block-1 input) to its block-0 launch there): the buffer is written by the backward although the pointer is const. */
+ * Floats per row: csmpn_cemlp_saved_floats_per_row(); for two-block Cl(5,0) CEMLPs of 9 .. 32 channels, for the
+ * two-block 8-channel Cl(3,0) EGCL shapes (edge model 14 -> 8 -> 8, node model 19 -> 8 -> 8) and for multi-block CEMLPs of
+ * the small algebras (n <= 3) outside the lane-kernel shapes this includes a second region of the same size behind the
+ * saved inputs that the backward uses as scratch (a block's phase / launch hands d/d(its input) to the previous block's
+ * there): the buffer is written by the backward although the pointer is const. */
 size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks);
 
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
