@@ -16,6 +16,7 @@ gradient's dot product with a seeded Gaussian direction (both runs) plus, for pa
                     dataset needs gudhi / DATAROOT).
   model_motion.npz, model_nba.npz  (`make_model_golden.py motion nba`, round 3) the motion-capture and NBA task models
                     (motion_cssmpnn.py, nba_cssmpnn.py) in the same form as the two above.
+  readout_hulls.npz (`make_model_golden.py readout`, round 3) the readout + loss stage of the hulls model on its own.
   stages_hulls.npz  (`make_model_golden.py stages`, round 3) embedding output and x behind every EGCL layer of the
                     hulls model on model_hulls.npz's parameters and batch.
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
@@ -305,7 +306,50 @@ def make_hulls_stages():
     print("hulls stages:", {k: v.shape for k, v in out.items() if k.endswith("rows")})
 
 
+def make_readout():
+    """Round 3: readout_hulls.npz - SURVEY.md §8(f)-2 on its own: the reference model's projection (its MVLinear, 28 -> 1),
+    scalar blade, global mean over the simplices of a graph and the MSE (hulls_cssmpnn.py:93,155-162) on a seeded
+    [S, 28, 32] tensor for a 2-graph batch; loss per graph, prediction, d/dx (whole, from the float64 run), d/d weight,
+    d/d bias of sum(w_g loss_g) for seeded graph weights."""
+    import torch.nn.functional as F
+    from torch_geometric.nn import global_mean_pool
+    out = {}
+    torch.manual_seed(101)
+    model32 = HullsCliffordSharedSimplicialMPNN()
+    batch = hulls_batch(21, 2)
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(int(batch.ptr[-1]), 28, 32, generator=g)
+    wl = torch.randn(2, generator=g)
+    out["x"], out["wl"], out["target"] = npy(x0), npy(wl), npy(batch.target)
+    out["x_ind_batch"], out["ptr"] = npy(batch.x_ind_batch), npy(batch.ptr)
+    sd = {k: v for k, v in model32.projection.state_dict().items() if "algebra." not in k}
+    for k, v in sd.items():
+        out["p/" + k] = npy(v)
+    for dt_name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dtype)
+        model = HullsCliffordSharedSimplicialMPNN()
+        full = model.projection.state_dict()
+        for k, v in sd.items():
+            full[k] = v.to(dtype)
+        model.projection.load_state_dict(full, strict=True)
+        x = x0.detach().clone().to(dtype).requires_grad_(True)
+        pred = global_mean_pool(model.projection(x)[:, :, 0], batch.x_ind_batch)
+        loss = F.mse_loss(pred.squeeze(-1), batch.target.to(dtype), reduction="none")
+        (loss * wl.to(dtype)).sum().backward()
+        out[f"{dt_name}/loss"], out[f"{dt_name}/pred"] = npy(loss), npy(pred.squeeze(-1))
+        out[f"{dt_name}/gx"] = npy(x.grad).astype(np.float32)
+        for k, p in model.projection.named_parameters():
+            gr = p.grad if p.grad is not None else torch.zeros_like(p)
+            out[f"{dt_name}/g/{k}"] = npy(gr).astype(np.float64 if dt_name == "f64" else np.float32)
+        torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, "readout_hulls.npz"), **out)
+    print("readout:", out["f32/loss"], out["f64/loss"])
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["readout"]:
+        make_readout()
+        sys.exit(0)
     if sys.argv[1:] == ["stages"]:
         make_hulls_stages()
         sys.exit(0)
