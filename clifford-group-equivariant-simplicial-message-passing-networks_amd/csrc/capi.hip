@@ -468,10 +468,10 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     C.phased = 0;
     int mirror_used = mirror;
     static const bool no_phased = getenv("CSMPN_NO_PHASED") && atoi(getenv("CSMPN_NO_PHASED"));
-    // Only for launches with many row tiles per workgroup (two passes over the tiles, the hand-over rows and the extra
-    // barriers cost more than the second tile buys on small batches: the md17 task model's 704-tile edge stage ran 6 % slower
-    // phased), and only where the all-blocks form already keeps a mirror (never away from the no-mirror variant).
-    const long phased_min_rows = 16L * 256 * 8;
+    // Only where the all-blocks form already keeps a mirror (never away from the no-mirror variant: switching the md17 task
+    // model's small node stages to the mirror form cost 6 % of its step) and for launches of at least one row tile per CU
+    // (measured on the md17 model, 11 266 adjacencies: step 4.62 ms with a 32 k-row threshold, 4.47 ms with 4 k or 8 k).
+    static const long phased_min_rows = getenv("CSMPN_PHASED_MIN_ROWS") ? atol(getenv("CSMPN_PHASED_MIN_ROWS")) : 16L * 256;
     if (bwd && use_saved && nblk > 1 && !ps && H == 1 && !no_phased && rows >= phased_min_rows && ch.var == VAR_GROUP &&
         general_phased_shape(n, blocks, nblk)) {
         int mirror_max = 0;
