@@ -472,7 +472,10 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     // model's small node stages to the mirror form cost 6 % of its step) and for launches of at least one row tile per CU
     // (measured on the md17 model, 11 266 adjacencies: step 4.62 ms with a 32 k-row threshold, 4.47 ms with 4 k or 8 k).
     static const long phased_min_rows = getenv("CSMPN_PHASED_MIN_ROWS") ? atol(getenv("CSMPN_PHASED_MIN_ROWS")) : 16L * 256;
-    if (bwd && use_saved && nblk > 1 && !ps && H == 1 && !no_phased && rows >= phased_min_rows && ch.var == VAR_GROUP &&
+    // From the no-mirror variant (per-tile float atomics onto the workgroup's copy) to the phased mirror form only for larger
+    // launches (M32 node stage, 10 k rows: 0.59 -> 0.48 ms; the md17 model's 940-row node stages lose).
+    const bool from_nm = ch.var == VAR_GROUP_NM && rows >= 2 * phased_min_rows;
+    if (bwd && use_saved && nblk > 1 && !ps && H == 1 && !no_phased && rows >= phased_min_rows && (ch.var == VAR_GROUP || from_nm) &&
         general_phased_shape(n, blocks, nblk)) {
         int mirror_max = 0;
         for (int k = 0; k < nblk; ++k) {
@@ -483,7 +486,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
         for (int sh = 0; sh < (allow_share ? 2 : 1); ++sh) {
             const TileLayout Lp = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps, sh != 0);
             const Choice cp = choose_variant(MT, (size_t)Lp.total * 4, (size_t)mirror_max * 4, (size_t)wstore * 4, bwd, ps);
-            if (cp.var == VAR_GROUP && resident(cp) > resident(ch)) {
+            if (cp.var == VAR_GROUP && (resident(cp) > resident(ch) || (from_nm && !C.phased))) {
                 L = Lp; ch = cp; C.share_inz = sh; C.phased = 1; mirror_used = mirror_max;
             }
         }
