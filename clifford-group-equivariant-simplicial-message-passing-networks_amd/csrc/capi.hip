@@ -965,8 +965,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     if (det_bytes && grid > kDetGroups) grid = kDetGroups;
     static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
     if (debug)
-        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d share=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
-                mode, (int)bwd, plan.var, (int)plan.ps, Cd.share_inz, plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
+        fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d share=%d phased=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
+                mode, (int)bwd, plan.var, (int)plan.ps, Cd.share_inz, (int)(bwd && Cd.phased), plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
                 Cd.tile_floats, Cd.mirror_floats, io.rows);
     if (det_bytes) {
         // the kernels' accumulators = copy 0 of the zeroed region; workgroup b adds b * det_slice_floats

@@ -447,6 +447,45 @@ def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path):
         assert err < 2e-5, (i, err)
 
 
+_PHASED_SCRIPT = r"""
+import importlib, os, sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+pkg = importlib.import_module("clifford-group-equivariant-simplicial-message-passing-networks_amd")
+from oracle import ref_path as O
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+metric, C, N, E = (1.0, 1.0, 1.0), 32, 9000, 12000
+layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="sum").to(dev)
+h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=3))
+gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(4)).to(dev)
+hh = h.clone().requires_grad_(True)
+gs = torch.autograd.grad(layer(hh, ei, ea, na), [hh] + list(layer.parameters()), gout)
+torch.cuda.synchronize()
+torch.save([g.cpu() for g in gs], sys.argv[2])
+"""
+
+
+def test_general_kernels_phased_backward(pkg, tmp_path):
+    """The block-by-block backward of the general row-tile kernels (md17's layer shape: Cl(3,0), 32 channels, aggr = sum;
+    12 000 edges: the mirror form with two row tiles per workgroup; 9 000 nodes: from the no-mirror variant to the phased
+    mirror form) against the all-blocks backward of the same library (CSMPN_NO_PHASED=1), each in its own process; the
+    dispatch log must show which form ran."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs, logs = {}, {}
+    for tag, extra in (("phased", {"CSMPN_DEBUG": "1"}), ("whole", {"CSMPN_NO_PHASED": "1", "CSMPN_DEBUG": "1"})):
+        f = str(tmp_path / f"g_{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", _PHASED_SCRIPT, root, f], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[tag], logs[tag] = torch.load(f), r.stderr
+    assert "mode=1 bwd=1 var=1 ps=0 share=1 phased=1" in logs["phased"] and "mode=2 bwd=1 var=1 ps=0 share=0 phased=1" in logs["phased"], logs["phased"][-1500:]
+    assert "phased=1" not in logs["whole"]
+    for i, (a, b) in enumerate(zip(outs["phased"], outs["whole"])):
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        assert err < 2e-5, (i, err)
+
+
 def test_wide_kernels_reproducible_for_fixed_inputs(pkg):
     """The wide parity-lane node / edge stages on fixed inputs: outputs, every data gradient and the dense weight
     gradients (per-workgroup slices + fixed-order reduction) are bit-identical from run to run - no race between the
