@@ -459,7 +459,12 @@ layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, nod
 h, ei, ea, na = (t.to(dev) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=3))
 gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(4)).to(dev)
 hh = h.clone().requires_grad_(True)
-gs = torch.autograd.grad(layer(hh, ei, ea, na), [hh] + list(layer.parameters()), gout)
+gs = list(torch.autograd.grad(layer(hh, ei, ea, na), [hh] + list(layer.parameters()), gout))
+# a standalone three-block CEMLP (two hand-over slots)
+mlp = pkg.CEMLP(pkg.CliffordAlgebra(metric), 10, 32, 32, n_layers=3).to(dev)
+x = torch.randn(9000, 10, 8, generator=torch.Generator().manual_seed(5)).to(dev).requires_grad_(True)
+gy = torch.randn(9000, 32, 8, generator=torch.Generator().manual_seed(6)).to(dev)
+gs += list(torch.autograd.grad(mlp(x), [x] + list(mlp.parameters()), gy))
 torch.cuda.synchronize()
 torch.save([g.cpu() for g in gs], sys.argv[2])
 """
@@ -480,6 +485,8 @@ def test_general_kernels_phased_backward(pkg, tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         outs[tag], logs[tag] = torch.load(f), r.stderr
     assert "mode=1 bwd=1 var=1 ps=0 share=1 phased=1" in logs["phased"] and "mode=2 bwd=1 var=1 ps=0 share=0 phased=1" in logs["phased"], logs["phased"][-1500:]
+    assert "mode=0 bwd=1" in logs["phased"] and any("mode=0 bwd=1" in l and "phased=1" in l for l in logs["phased"].splitlines()), \
+        "the three-block CEMLP did not take the phased form"
     assert "phased=1" not in logs["whole"]
     for i, (a, b) in enumerate(zip(outs["phased"], outs["whole"])):
         err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
