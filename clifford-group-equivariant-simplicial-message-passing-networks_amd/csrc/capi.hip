@@ -625,7 +625,6 @@ bool general_phased_shape(int n, const csmpn_block_params* blocks, int nblk) {
         if (blocks[1].out_features == ch && blocks[1].in_features == ch) {
             if (cl_shape(n, blocks, nblk)) return false;
             if (has_cemlp_rl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_rl_n3(MODE_NODE, nblk, ch, i0)) return false;
-            if (has_cemlp_cm_n3(MODE_EDGE, nblk, ch, i0, false) || has_cemlp_cm_n3(MODE_NODE, nblk, ch, i0, false)) return false;
         }
     }
     return true;
@@ -706,7 +705,8 @@ bool cl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return true;
 }
 
-// channel-MFMA kernels (cemlp_cm.hpp): Cl(3,0), two blocks of 16 channels, the EGCL attribute widths of S2.
+// channel-MFMA kernels (cemlp_cm.hpp): Cl(3,0), two blocks of 16 channels (S2) or - forward only - 32 channels (md17), the EGCL
+// attribute widths (6, 3).
 // CSMPN_NO_CM=1 leaves these shapes to the row-per-lane kernels (A/B measurements, parity tests of both paths).
 bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
     static const bool off = getenv("CSMPN_NO_CM") && atoi(getenv("CSMPN_NO_CM"));
@@ -858,7 +858,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         int channels = 0, i0 = 0;
         if (cm_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
             const long tiles = (io.rows + 15) / 16;   // tile t (16 rows) belongs to wave t % (4 grid)
-            const long cap = bwd ? kCmMaxBwdGroups : kCmMaxFwdGroups;
+            const long cap = bwd ? kCmMaxBwdGroups : (channels == 16 ? kCmMaxFwdGroups : 256);   // 32 channels: one workgroup per CU
             const long groups = (tiles + 3) / 4;
             const unsigned grid = (unsigned)(groups < cap ? groups : cap);
             if (bwd) {

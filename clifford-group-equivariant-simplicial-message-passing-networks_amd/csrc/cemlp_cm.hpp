@@ -478,7 +478,7 @@ CSMPN_DEV void cm_scatter(const float* sc, int t_add, int t_sub, float* table, i
 // ---------------------------------------------------------------------------------
 // forward kernel: NBLK blocks (1 or 2), all C channels wide. Tile t (16 rows) belongs to wave t mod (4 gridDim).
 template <class ALG, int C, int MODE, int NBLK, int NA>
-__global__ void __launch_bounds__(64 * kCmWaves, CM_FWD_OCC) cemlp_cm_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp_cm_fwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);

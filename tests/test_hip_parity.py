@@ -368,10 +368,11 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_sc
     return errs
 
 
-# the shapes served by the row-per-lane (Cl(3,0), 8 / 16 channels) and parity-lane (Cl(5,0), Cl(4,1); 8 channels and the
+# the shapes served by the (row, channel)-per-lane / channel-MFMA / row-per-lane (Cl(3,0), 8 / 16 channels; 32 channels: channel-MFMA
+# forward, general backward) and parity-lane (Cl(5,0), Cl(4,1); 8 channels and the
 # wide 16 / 24 / 28 / 32-channel variants) kernels: tile tails (rows not a multiple of the 32 / 16 / 4 rows of a wave tile), fewer rows than one tile,
 # aggr = sum, no residual, attribute gradients
-@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0, 1.0, 1.0), 16), ((1.0,) * 5, 8),
+@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 8), ((1.0, 1.0, 1.0), 16), ((1.0, 1.0, 1.0), 32), ((1.0,) * 5, 8),
                                       ((1.0, 1.0, 1.0, 1.0, -1.0), 8),
                                       # wide parity-lane kernels (one wave per 8 channels): 2, 3 and 4 groups, a partial last group
                                       ((1.0,) * 5, 28), ((1.0, 1.0, 1.0, 1.0, -1.0), 16), ((1.0,) * 5, 24),
