@@ -45,6 +45,9 @@
 namespace csmpn {
 
 CSMPN_DEV f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+// Compiler barrier between the 16-byte vector stores into the staging tile and the float reads of the same LDS bytes (the
+// two access types carry different alias information: cemlp_cm.hpp met the reordering this allows). Costs no instruction.
+#define RL_LDS_ORDER() asm volatile("" ::: "memory")
 CSMPN_DEV f4 ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 
 constexpr int kRlWaves = 4;        // waves per workgroup
@@ -1276,7 +1279,9 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                 if (io.row_store) {
                     if (valid) rl_store_t<ALG>(out, io.agg + (size_t)lrow * ROW + ge.og * PIECE, 1.0f);
                 } else {
+                    RL_LDS_ORDER();
                     rl_store_t<ALG>(out, sc + ge.g_st, 1.0f);
+                    RL_LDS_ORDER();
                     rl_scatter<GE, ROW, false>(sc, valid ? i_dst : -1, -1, io.agg, ge.lane);
                 }
                 ge.stamp(18);
@@ -1365,7 +1370,9 @@ __global__ void __launch_bounds__(64 * kRlWaves, BWD ? 1 : 2) cemlp_rl_kernel(co
                     if (io.row_store) {
                         if (valid) rl_store_t<ALG>(gx[0], io.gx[0] + (size_t)lrow * ROW + ge.og * PIECE, 1.0f);
                     } else {
+                        RL_LDS_ORDER();
                         rl_store_t<ALG>(gx[0], sc + ge.g_st, 1.0f);
+                        RL_LDS_ORDER();
                         rl_scatter<GE, ROW, true>(sc, valid ? i_dst : -1, valid ? i_src : -1, io.gx[0], ge.lane);
                     }
                 }
