@@ -759,7 +759,9 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     if (C.nblk < 1 || C.nblk > 2) return false;
     const int ch = C.b[0].O;
     static const bool plw8 = getenv("CSMPN_PLW8") && atoi(getenv("CSMPN_PLW8"));   // 8 channels: wide kernels with one group
-    // 8 channels belong to cemlp_pl.hpp (4-5x faster there); the one-group wide kernels take them only on request
+    // 8 channels belong to cemlp_pl.hpp; the one-group wide kernels take them only on request (round 2 measured them 4-5x
+    // slower - compiled for four waves per SIMD by mistake, 1.3 KB of scratch; with the launch bounds repaired they are on a
+    // par: S3 1.339 against 1.333 ms)
     if ((ch <= 8 && !(ch == 8 && plw8)) || ch > 32 || !C.b[0].w1_sub) return false;
     if (C.nblk == 2 && (C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub)) return false;
     int na = 0;
