@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--points", type=int, default=8)
-    ap.add_argument("--model", default="hulls", choices=["hulls", "md17"])
+    ap.add_argument("--model", default="hulls", choices=["hulls", "md17", "motion"])
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     args = ap.parse_args()
@@ -43,6 +43,24 @@ def main():
         batch = cx.collate([cx.hulls_example(rng.standard_normal((args.points, 5)).astype(np.float32))
                             for _ in range(args.batch)]).to(dev)
         features = ["input", "target"]
+    elif args.model == "motion":
+        # motion-capture-shaped batch (motion_cssmpnn.py: Cl(3,0), 16 channels, 4 layers, aggr = mean): 31 joints per
+        # skeleton, Vietoris-Rips complex of the joint positions, one frame of positions / velocities
+        V, graphs = 31, []
+        for _ in range(args.batch):
+            base = (1.6 * rng.standard_normal((V, 3))).astype(np.float32)
+            c = cx.rips_complex(base, dis=1.6, max_dim=2)
+            S = c.n_simplices
+            pos, vel = torch.zeros(S, 3), torch.zeros(S, 3)
+            pos[:V] = torch.from_numpy(base)
+            vel[:V] = 0.1 * torch.from_numpy(rng.standard_normal((V, 3)).astype(np.float32))
+            c.features.update(pos=pos, vel=vel)
+            graphs.append(c)
+        batch = cx.collate(graphs)
+        batch.y = torch.cat([g.features["pos"][: g.n_vertices] + 0.1 * torch.randn(g.n_vertices, 3) for g in graphs], dim=0)
+        batch._names.append("y")
+        batch = batch.to(dev)
+        features = ["pos", "vel", "y"]
     else:
         # MD17-shaped batch (md17_cssmpnn.py; csmpn/configs/md17.yaml: Cl(3,0), 32 channels, 5 layers): 21 atoms
         # (aspirin), 10 frames, Vietoris-Rips complex of the first frame, random positions / velocities / charges
@@ -63,7 +81,7 @@ def main():
         batch = batch.to(dev)
         features = ["loc", "vel", "charges", "y"]
     torch.manual_seed(0)
-    model = (M.HullsSimplicialMPNN() if args.model == "hulls" else M.MD17SimplicialMPNN()).to(dev)
+    model = {"hulls": M.HullsSimplicialMPNN, "md17": M.MD17SimplicialMPNN, "motion": M.MotionSimplicialMPNN}[args.model]().to(dev)
     # the reference trains with torch.optim.Adam (csmpn/configs/hulls.yaml); fused=True is the same update in one
     # multi-tensor kernel (the default foreach path with capturable=True issues ~300 per-tensor div kernels: 1.5 ms)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True,
@@ -94,7 +112,9 @@ def main():
         gs.step()
     torch.cuda.synchronize()
     graph_ms = (time.perf_counter() - t0) * 1e3 / args.steps
-    print(json.dumps({"model": "hulls (Cl(5,0), 28 channels, 3 layers)" if args.model == "hulls" else "md17 (Cl(3,0), 32 channels, 5 layers)", "graphs_per_batch": args.batch,
+    label = {"hulls": "hulls (Cl(5,0), 28 channels, 3 layers)", "md17": "md17 (Cl(3,0), 32 channels, 5 layers)",
+             "motion": "motion (Cl(3,0), 16 channels, 4 layers)"}[args.model]
+    print(json.dumps({"model": label, "graphs_per_batch": args.batch,
                       "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
                       "fused_grad_accumulation": not args.no_fused_grads, "fused_adam": not args.no_fused_adam, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
                       "loss": float(gs.loss.detach())}))
