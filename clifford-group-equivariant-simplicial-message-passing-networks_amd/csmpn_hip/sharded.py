@@ -28,6 +28,8 @@ the bytes of A, and both collectives use all xGMI links at once.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -47,7 +49,7 @@ class ShardPlan:
     def __init__(self, edge_index_local, n_nodes, backend=ops.HipBackend, group=None):
         self.csr = backend.build_csr(edge_index_local, n_nodes)
         deg = self.csr.deg.clone()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _multi(group):
             dist.all_reduce(deg, op=dist.ReduceOp.SUM, group=group)
         self.deg = deg
         self.n_nodes = n_nodes
@@ -60,7 +62,7 @@ class _ShardedEgclFn(torch.autograd.Function):
         ne = spec.edge.nblk * ops.NP
         pe, pn = params[:ne], params[ne:]
         agg, st_e = backend.edge_forward(spec, plan.csr, h, edge_attr, pe)
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _multi(group):
             dist.all_reduce(agg, op=dist.ReduceOp.SUM, group=group)
         out, st_n = backend.node_forward(spec, plan.deg, h, agg, node_attr, pn)
         ctx.st_e, ctx.st_n = st_e, st_n
@@ -93,7 +95,7 @@ class _ShardedEgclFn(torch.autograd.Function):
         gh_edge = torch.zeros_like(h)
         g_ea, views_e = backend.edge_backward(spec, plan.csr, h, edge_attr, pe, g_agg, gh_edge,
                                               ctx.needs_input_grad[1], ctx.st_e)
-        if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if _multi(group):
             # one collective: [d/dh | edge-model parameter gradients]
             pieces = [gh_edge.reshape(-1)] + [v.reshape(-1) for v in views_e if v is not None]
             packed = torch.cat(pieces)
@@ -153,7 +155,7 @@ class GraphedShardedStep:
         self.pe = layer.edge_model.flat_params()
         self.pn = layer.node_model.flat_params()
         self.h, self.ea, self.na, self.gout = h.detach(), edge_attr_local, node_attr, gout
-        self._multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        self._multi = _multi(self.group)
         h_, ea, na, pe, pn = self.h, self.ea, self.na, self.pe, self.pn
 
         # N > 1: the edge forward runs as two launches over the two halves of the target-sorted
@@ -296,6 +298,24 @@ def _world(group):
     return 1, 0
 
 
+def _multi(group=None) -> bool:
+    """True when the collectives have to be issued: a process group of more than one rank - or of ONE rank with
+    CSMPN_FORCE_COLLECTIVES=1. The second form is the RCCL rehearsal of tests/test_sharded_gpu.py (round 4): a one-GPU box
+    cannot hold two RCCL ranks, but with a world-size-1 `nccl` group every all_reduce / all_gather_into_tensor /
+    reduce_scatter_tensor of this module is posted to RCCL exactly as it would be on N ranks (padded layouts included)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("CSMPN_FORCE_COLLECTIVES", "0") == "1"
+
+
+def _collective_device(group, fallback):
+    """Device a small bookkeeping tensor must live on to go through the group's collectives: NCCL = RCCL moves device
+    memory only (a CPU edge_index would otherwise fail in DstPlan / ShardPlan), gloo takes either."""
+    if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend(group)).lower():
+        return torch.device("cuda", torch.cuda.current_device())
+    return fallback
+
+
 def _fused_collectives(group) -> bool:
     """The single-tensor collectives (all_gather_into_tensor / reduce_scatter_tensor) exist on NCCL = RCCL; gloo takes the
     list / all-reduce forms. Decided ONCE from the backend name: a per-call try / except would let a rank-local
@@ -354,7 +374,7 @@ def _reduce_scatter_rows_async(part, full, group) -> _Pending:
 def agree_all(local_ok: bool, group=None, device=None) -> bool:
     """True iff the condition holds on EVERY rank (all-reduce MIN of a flag). For choices that change which
     collectives a rank issues: they must come out the same everywhere, or the ranks post mismatched collectives."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _multi(group):
         return bool(local_ok)
     flag = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
@@ -367,17 +387,27 @@ class DstPlan:
     and the index tables that move rows between the natural layout [N] and the padded layout [W * per] the
     equal-size collectives need (per = longest slice; pad rows read a zero row / are dropped)."""
 
-    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None, balance=True):
+    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None, balance=True, max_pad=1.5):
         self.world, self.rank = _world(group)
+        self.multi = _multi(group)      # collectives are issued (world > 1, or the forced world-size-1 rehearsal)
         dev = edge_index.device
         dst = edge_index[1]
         if balance and self.world > 1:
             deg_all = torch.bincount(dst, minlength=n_nodes)
             self.cuts = balanced_node_cuts(deg_all, self.world)
+            # The collectives move the padded layout W x per (per = longest slice in NODES): on complexes whose in-degree
+            # is skewed (vertex / edge / triangle rows) cuts by in-degree alone let per grow towards N. Bound it: no slice
+            # longer than max_pad x N / W nodes (round-3 ADVICE) - the edge balance gives way first.
+            cap = max(1, int(-(-n_nodes * max_pad // self.world)))
+            for r in range(1, self.world):          # left to right: a slice that is too long hands nodes to the next one
+                self.cuts[r] = min(self.cuts[r], self.cuts[r - 1] + cap)
+            for r in range(self.world - 1, 0, -1):  # ... and right to left for the last slices
+                self.cuts[r] = max(self.cuts[r], self.cuts[r + 1] - cap)
         else:
             self.cuts = [node_bounds(n_nodes, self.world, r)[0] for r in range(self.world)] + [n_nodes]
         self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
         self.per = max(1, max(self.cuts[r + 1] - self.cuts[r] for r in range(self.world)))
+        self.pad_ratio = self.world * self.per / max(1, n_nodes)   # rows the collectives move / rows that exist
         mine = (dst >= self.lo) & (dst < self.hi)
         self.edge_ids = torch.nonzero(mine, as_tuple=False).squeeze(1)
         self.csr = backend.build_csr(edge_index[:, self.edge_ids].contiguous(), n_nodes)
@@ -403,8 +433,8 @@ class DstPlan:
         self.pos_of_node = pos.to(dev)
         self.node_of_pos = src.to(dev)
         self.edges_per_rank = None
-        if self.world > 1:
-            cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        if self.multi:   # a collective: plan() must be called on every rank of the group
+            cnt = torch.zeros(self.world, dtype=torch.int64, device=_collective_device(group, dev))
             cnt[self.rank] = int(self.edge_ids.numel())
             dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
             self.edges_per_rank = cnt.tolist()
@@ -461,7 +491,7 @@ class _DstPartStackFn(torch.autograd.Function):
             agg, st_e = backend.edge_forward(spec, plan.csr, x, edge_attr_local, pe)      # complete on [lo, hi)
             out_loc, st_n = backend.node_forward(spec, deg_loc, x[lo:hi].contiguous(), agg[lo:hi].contiguous(), na_loc, pn)
             hs.append(x); aggs.append(agg); st.append((st_e, st_n))
-            if plan.world > 1:
+            if plan.multi:
                 padded = out_loc.new_empty((plan.world * plan.per,) + tuple(out_loc.shape[1:]))
                 _all_gather_rows(padded, plan.pad_slice(out_loc), group)
                 x = plan.from_padded(padded)
@@ -521,7 +551,7 @@ class _DstPartStackFn(torch.autograd.Function):
                 g_ea_total = g_ea if g_ea_total is None else g_ea_total + g_ea
             if g_na_loc is not None:
                 g_na_loc_total = g_na_loc if g_na_loc_total is None else g_na_loc_total + g_na_loc
-            if plan.world > 1:
+            if plan.multi:
                 g_pad = gh_edge.new_empty((plan.per,) + tuple(gh_edge.shape[1:]))
                 _reduce_scatter_rows(g_pad, plan.to_padded(gh_edge), group)
                 g_loc = g_pad[:hi - lo] + gh_node
@@ -531,14 +561,14 @@ class _DstPartStackFn(torch.autograd.Function):
                 g_loc = gh_edge[lo:hi]
         gh = None
         if ctx.needs_input_grad[0]:
-            if plan.world > 1:
+            if plan.multi:
                 padded = g_loc.new_empty((plan.world * plan.per,) + tuple(g_loc.shape[1:]))
                 _all_gather_rows(padded, plan.pad_slice(g_loc), group)
                 gh = plan.from_padded(padded)
             else:
                 gh = gh_full_single
         g_na = None
-        if plan.world > 1:
+        if plan.multi:
             live = [v for v in views_all if v is not None]
             if live:
                 flat = torch.cat([v.reshape(-1) for v in live])
@@ -745,7 +775,7 @@ class DstPartitionedStack(torch.nn.Module):
             params += lp
             counts.append(len(lp))
             specs.append(layer.spec())
-        fn = _DstPartStackOverlapFn if (self.overlap and plan.world > 1) else _DstPartStackFn
+        fn = _DstPartStackOverlapFn if (self.overlap and plan.multi) else _DstPartStackFn
         return fn.apply(h, edge_attr_local, node_attr, tuple(specs), plan, self.backend, self.group, tuple(counts), *params)
 
 
@@ -763,7 +793,7 @@ class GraphedDstStep:
         pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
         self.h = h_ = h.detach()
         lo, hi = plan.lo, plan.hi
-        self._multi = plan.world > 1
+        self._multi = plan.multi
         na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
         h_loc, deg_loc, gout_loc = h_[lo:hi], plan.deg[lo:hi].contiguous(), gout[lo:hi].contiguous()
         self.out_all = h_.new_empty((plan.world * plan.per,) + tuple(h_.shape[1:]))   # all-gather target (padded layout)
@@ -837,7 +867,7 @@ class GraphedDstStackStep:
         pns = [l.node_model.flat_params() for l in layers]
         lo, hi = plan.lo, plan.hi
         n = hi - lo
-        self._multi = plan.world > 1
+        self._multi = plan.multi
         h0 = h.detach().contiguous()
         na_loc = None if node_attr is None else node_attr[lo:hi].contiguous()
         deg_loc = plan.deg[lo:hi].contiguous()

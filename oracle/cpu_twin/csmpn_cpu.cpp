@@ -19,6 +19,15 @@
 #include <omp.h>
 #endif
 
+#ifdef CSMPN_CPU_REAL64
+// float64 build of this same source (oracle/_build/libcsmpn_cpu64.so, round 4): every `float` from here on - the API's
+// pointers and the descriptor structs included - is a double, so the library takes and returns float64 arrays and computes
+// in float64. It is the TRUTH of the full-size GPU parity tests (tests/test_full_size_twin.py); the float32 build next to
+// it is their yardstick. The f-suffixed literals that remain are exactly representable or are the reference's own
+// float32 constants (1e-16f, 1e-6f).
+#define float double
+#endif
+
 #include "../../include/csmpn_cpu.h"
 
 namespace {
@@ -91,7 +100,7 @@ bool build_tables(const float* metric, int n, Tables& t) {
 inline float sigmoid(float x) { return 1.0f / (1.0f + std::exp(-x)); }
 inline float smooth_abs_sqrt(float q) { return std::sqrt(std::sqrt(q * q + 1e-16f)); }
 constexpr float kEps = 1e-6f;
-const float kInvSqrt2 = 0.70710678118654752440f;
+const float kInvSqrt2 = 0.70710678118654752440;
 
 // forward state of one block on one row
 struct State {

@@ -44,6 +44,34 @@ def test_twin_egcl_vs_reference_fixture(name, variant):
 
 
 @pytest.mark.parametrize("name", ALGS)
+@pytest.mark.parametrize("variant", ["sum_res1_ag1", "mean_res0_ag0", "noattr"])
+def test_twin_float64_build_vs_reference_float64_fixture(name, variant):
+    """The float64 build of the twin (oracle/_build/libcsmpn_cpu64.so: the truth of tests/test_full_size_twin.py) against
+    the reference's own float64 run: same parameters and inputs (the float32 ones, widened), agreement to rounding."""
+    g = np.load(os.path.join(GOLD, f"egcl_{name}.npz"))
+    metric = np.load(os.path.join(GOLD, f"tables_{name}.npz"))["metric"]
+    f32, f64 = f"f32/{variant}", f"f64/{variant}"
+    p = {k[len(f32) + 3:]: g[k] for k in g.files if k.startswith(f32 + "/p/")}
+    noattr = variant == "noattr"
+    ag = variant.endswith("ag1")
+    for k in ("h", "gout"):
+        assert np.array_equal(g[f"{f32}/{k}"].astype(np.float64), g[f"{f64}/{k}"]), k
+    res = cpu_twin.egcl_layer(metric, p, g[f"{f32}/h"], g[f"{f32}/edge_index"],
+                              None if noattr else g[f"{f32}/edge_attr"], None if noattr else g[f"{f32}/node_attr"],
+                              aggr="mean" if noattr else variant.split("_")[0], residual="res0" not in variant,
+                              gout=g[f"{f32}/gout"], want_attr_grads=ag, threads=2, real64=True)
+    assert res["out"].dtype == np.float64
+    tol = 1e-7 if (metric < 0).any() else 1e-10
+    assert rel(res["out"], g[f"{f64}/y"]) <= tol
+    assert rel(res["gh"], g[f"{f64}/gh"]) <= tol
+    if ag:
+        assert rel(res["g_edge_attr"], g[f"{f64}/g_edge_attr"]) <= tol
+        assert rel(res["g_node_attr"], g[f"{f64}/g_node_attr"]) <= tol
+    for k, v in res["grads"].items():
+        assert v.dtype == np.float64 and rel(v, g[f"{f64}/g/{k}"]) <= tol, k
+
+
+@pytest.mark.parametrize("name", ALGS)
 @pytest.mark.parametrize("tag", ["cemlp1_C3", "cemlp2_C8"])
 def test_twin_cemlp_vs_reference_fixture(name, tag):
     g = np.load(os.path.join(GOLD, f"layers_{name}.npz"))
