@@ -599,11 +599,12 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     cl = cm > cl ? cm : cl;
     return cl > rl ? cl : rl;
 }
-// The channel-MFMA backward (cemlp_cm.hpp) is correct but slower than the row-per-lane backward it would replace
-// (measurements at CM_BWD_OCC in cemlp_cm.hpp): CSMPN_CM_BWD=1 selects it. Read ONCE per process: the size of the saved
-// region the caller allocates (csmpn_cemlp_saved_floats_per_row) depends on it and must not change under a live plan.
+// The channel-MFMA backward (cemlp_cmb.hpp, round 4: two waves per SIMD, tensors parked in LDS) serves the 16-channel
+// Cl(3,0) layers; CSMPN_NO_CM_BWD=1 leaves them to the row-per-lane backward (A/B measurements). Read ONCE per process: the
+// size of the saved region the caller allocates (csmpn_cemlp_saved_floats_per_row) depends on it and must not change
+// under a live plan.
 bool cm_bwd_enabled() {
-    static const bool on = getenv("CSMPN_CM_BWD") && atoi(getenv("CSMPN_CM_BWD"));
+    static const bool on = !(getenv("CSMPN_NO_CM_BWD") && atoi(getenv("CSMPN_NO_CM_BWD")));
     return on;
 }
 // the (row, channel)-per-lane backward hands d/d(block-1 input) from its block-1 launch to its block-0 launch through
@@ -726,7 +727,7 @@ bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     *i0 = C.b[0].I;
     if (!has_cemlp_cm_n3(mode, C.nblk, ch, C.b[0].I, bwd)) return false;
     if (bwd) {
-        if (!cm_bwd_enabled()) return false;   // opt-in: slower than the row-per-lane backward
+        if (!cm_bwd_enabled()) return false;
         const size_t pb = cemlp_cm_partial_floats_n3(mode, C.nblk, ch, C.b[0].I) * sizeof(float) * kCmSliceCap;
         if (!plan.workspace || plan.workspace_bytes < pb) return false;
     }
@@ -1347,7 +1348,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
                             float* save_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
-    if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
+    if (attr_channels > 0 && !edge_attr && E > 0) return fail(CSMPN_ERR_INVALID, "edge_attr is null");   // an empty edge list carries no attribute rows
     if (channels + attr_channels != blocks[0].in_features)
         return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
     const int D = 1 << n;
@@ -1375,7 +1376,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
                              size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
-    if (attr_channels > 0 && !edge_attr) return fail(CSMPN_ERR_INVALID, "edge_attr is null");
+    if (attr_channels > 0 && !edge_attr && E > 0) return fail(CSMPN_ERR_INVALID, "edge_attr is null");   // an empty edge list carries no attribute rows
     if (channels + attr_channels != blocks[0].in_features)
         return fail(CSMPN_ERR_INVALID, "edge model in_features %d != %d + %d", blocks[0].in_features, channels, attr_channels);
     Plan plan;

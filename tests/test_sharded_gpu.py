@@ -444,6 +444,9 @@ def _worker_rccl_world1(port, q):
         res["G.y"], res["G.gh"] = rel(step.out, x.detach()), rel(step.gh_loc, g2[0])
         res["G.params"] = rel(step.flat, torch.cat([by_id[id(p)].reshape(-1) for p in flatp]))
         q.put(res)
+    except Exception as e:   # the parent must not wait for a result that will never come
+        import traceback
+        q.put({"error": f"{type(e).__name__}: {e}\n{traceback.format_exc()}"})
     finally:
         dist.destroy_process_group()
 
@@ -453,8 +456,9 @@ def test_rccl_world1_sharded_paths():
     q = ctx.Queue()
     p = ctx.Process(target=_worker_rccl_world1, args=(_free_port(), q))
     p.start()
-    res = q.get(timeout=600)
+    res = q.get(timeout=300)
     p.join(timeout=120)
+    assert "error" not in res, res["error"]
     assert p.exitcode == 0
     assert res.pop("forced") == 0.0 and res.pop("fused") == 0.0
     for k, v in res.items():
