@@ -44,6 +44,10 @@
 
 namespace csmpn {
 
+// phase marker in the generated code (a comment: no instruction); tools/asm_phases.py counts instructions and scratch
+// accesses between markers
+#define CB_MARK(n) asm volatile("; cb-phase " #n ::: "memory")
+
 constexpr int kCbWaves = 8;        // waves per workgroup: two per SIMD
 constexpr int kCbSlot = 2048;      // floats of one tensor slot (16 rows x 16 channels x 8 blades)
 
@@ -360,6 +364,23 @@ CSMPN_DEV void cb_gp_bwd(const float (&ggp)[8], const float (&zf)[8], const floa
     });
 }
 
+// the block's input rows of one tile: requested in one go (issue), turned into chunks later (finish)
+template <class ALG, int C, int MODE, int NA, int K>
+struct CbIn {
+    using TF = CmTab<C, MODE, NA, K>;
+    static constexpr int ROW = C * ALG::D;
+    CmRaw<ALG, C, MODE, NA> raw;   // block 0: gathered / concatenated rows
+    CmPiece sp;                    // later blocks: the saved block input
+    CSMPN_DEV void issue(const RowIO& io, const CmTile<MODE>& T, int q) {
+        if constexpr (K == 0) raw.issue(io, T, q);
+        else sp.load(io.saved + (size_t)T.lrow * ROW + q * ALG::D);
+    }
+    CSMPN_DEV void finish(f4 (&x)[TF::NCH][8], const CmTile<MODE>& T) const {
+        if constexpr (K == 0) raw.template finish<TF>(x, T);
+        else cm_unpack(x[0], sp);
+    }
+};
+
 // persistent sums of one wave over its tiles of one block
 template <int NCH>
 struct CbAcc {
@@ -381,7 +402,7 @@ struct CbAcc {
 // backward of block K over this wave's tiles. tab: the block's tables, P / W: this wave's slots, work: all waves' slots
 // (the end-of-block image lies over them).
 template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-__device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stamp) {
+__device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClStamp& stamp) {
     static_assert(C == 16, "one channel group");
     using TF = CmTab<C, MODE, NA, K>;
     using PT = ClPart<ALG, C, TF::I>;
@@ -403,25 +424,47 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
     A.zero();
     const long ntiles = (io.rows + kCmRows - 1) / kCmRows;
     const long tstride = (long)gridDim.x * kCbWaves;
-    for (long tile = (long)blockIdx.x * kCbWaves + wave; tile < ntiles; tile += tstride) {
+#ifdef CSMPN_STAMPS
+    const unsigned long long kstart = __builtin_amdgcn_s_memtime();
+#endif
+    // Tiles of a workgroup: 8 consecutive ones per round of the grid. WHICH wave takes which is decided at run time (a
+    // counter in LDS) unless the deterministic flag is set: the two waves of a SIMD run the same program and the vector
+    // issue goes to the older one first - with a static map waves 0-3 finished their tiles ~20 % early and idled at the
+    // end-of-block barrier while waves 4-7 ran alone (measured with per-wave stamps; alternating s_setprio did not level
+    // it). Dynamic claims keep every wave busy to the end; the price is that a wave's partial sums - and so the last
+    // bits of the parameter gradients - depend on the timing (as the float atomics of the scatter already do).
+    // Software pipeline (as the forward): the rows of tile t + 1 are requested BEFORE the stores and atomics of tile t (a
+    // load queued behind an atomic waits for its acknowledgement); its indices were requested at the start of tile t.
+    const bool dynamic = !io.row_store;
+    long seq = wave;   // static map: this wave's next position in the workgroup's tile sequence
+    auto claim = [&]() -> long {
+        long n;
+        if (dynamic) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(ctr, 1);
+            n = __builtin_amdgcn_readfirstlane(c);
+        } else {
+            n = seq;
+            seq += kCbWaves;
+        }
+        return (n >> 3) * tstride + (long)blockIdx.x * kCbWaves + (n & 7);
+    };
+    long tile = claim();
+    CmTile<MODE> T, Tn;
+    T.template load<NA>(io, tile, r);
+    CbIn<ALG, C, MODE, NA, K> in;
+    in.issue(io, T, q);
+    while (tile < ntiles) {
         asm volatile("" ::: "memory");   // the tables are loop invariant: keep their reads inside the loop
-        CmTile<MODE> T;
-        T.template load<NA>(io, tile, r);
+        const long tile_next = claim();
+        Tn.template load<NA>(io, tile_next, r);
         // ---- the block's input -> y = W1 x; then d/d(out) is requested (it travels under the gates) and parked in W
         f4 y[8];
 #pragma unroll
         for (int d = 0; d < D; ++d) y[d] = f4{0.f, 0.f, 0.f, 0.f};
         {
             f4 x[NCH][8];
-            if constexpr (K == 0) {
-                CmRaw<ALG, C, MODE, NA> raw;
-                raw.issue(io, T, q);
-                raw.template finish<TF>(x, T);
-            } else {
-                CmPiece sp;
-                sp.load(io.saved + (size_t)T.lrow * ROW + q * D);
-                cm_unpack(x[0], sp);
-            }
+            in.finish(x, T);
             static_for<0, NCH>([&](auto ch) { cm_mix_one<ALG, TF::nstep(ch), GS1>(y, x[ch], ldsa + TF::w1(0, 0, ch)); });
         }
         CM_FENCE();
@@ -429,6 +472,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
         gp.load((kLast ? io.gy + (size_t)(MODE == MODE_EDGE ? (long)T.i_dst : T.lrow) * ROW : io.plw_g1 + (size_t)T.lrow * ROW) + q * D);
         asm volatile("" ::: "memory");
         stamp(1);
+        CB_MARK(1);
         // ---- forward again: z = gate(y) y -> P; R = WR z, s = (WL z + bL + gp(z, n(R))) / sqrt 2
         f4 R[8], s[8];
         float invMn;
@@ -471,6 +515,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
             invMn = fast_rcp(__builtin_fmaf(cm_q_sum(nlsum), 1.0f / float(C), kEps));
         }
         stamp(2);
+        CB_MARK(2);
         // ---- MVLayerNorm backward: d/d(out) (W) and s -> ggp = d/d(gp + linear_left output), written back to W per channel
         {
             float S = 0.f, dot[4];
@@ -509,9 +554,11 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
         }
         cb_sync();
         stamp(3);
+        CB_MARK(3);
         // ---- d/d(linear_left weight) = ggp^T z, both operands from the slots
         cb_wgrad<ALG>(A.wl, Wq, Pq, AD);
         stamp(4);
+        CB_MARK(4);
         // ---- geometric product + normalisation backward, per channel: R becomes d/dR, s becomes the product's d/dz
         {
             CbCollect<1> col;
@@ -530,6 +577,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
             });
         }
         stamp(5);
+        CB_MARK(5);
         // ---- d/dz += WL^T ggp (read back) + WR^T gR; gR -> W; d/d(linear_right weight) = gR^T z
         {
             f4 ggp[8];
@@ -540,29 +588,25 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
         cb_put(Wq, AD, R);
         cb_mix_t<ALG, GSC>(s, R, ldst + TF::wc(0, 0, 0, 0));
         cb_sync();
+        // the input again (the gates' argument y = W1 x; d/dW1's operand): requested here, it travels under the MFMAs below
+        asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
+        in.issue(io, T, q);
+        asm volatile("" ::: "memory");
         cb_wgrad<ALG>(A.wr, Wq, Pq, AD);
         cb_sync();
-        cb_put(Wq, AD, s);   // d/dz waits in W while the input is gathered again
+        cb_put(Wq, AD, s);   // d/dz waits in W meanwhile
         CM_FENCE();
         stamp(6);
-        // ---- the input again -> y (the gates' argument); its chunks go to P one after the other for d/dW1
-        asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
+        CB_MARK(6);
         f4 x[NCH][8];
-        if constexpr (K == 0) {
-            CmRaw<ALG, C, MODE, NA> raw;
-            raw.issue(io, T, q);
-            raw.template finish<TF>(x, T);
-        } else {
-            CmPiece sp;
-            sp.load(io.saved + (size_t)T.lrow * ROW + q * D);
-            cm_unpack(x[0], sp);
-        }
+        in.finish(x, T);
 #pragma unroll
         for (int d = 0; d < D; ++d) y[d] = f4{0.f, 0.f, 0.f, 0.f};
         static_for<0, NCH>([&](auto ch) { cm_mix_one<ALG, TF::nstep(ch), GS1>(y, x[ch], ldsa + TF::w1(0, 0, ch)); });
         cb_put(Pq, AD, x[0]);   // z is no longer needed
         CM_FENCE();
         stamp(7);
+        CB_MARK(7);
         // ---- MVSiLU backward, per channel, in place in W: d/dz becomes d/dy
         {
             CbCollect<7> col;
@@ -586,6 +630,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
         }
         cb_sync();
         stamp(8);
+        CB_MARK(8);
         // ---- d/d(MVLinear weight) = gy^T x, chunk by chunk through P
         static_for<0, NCH>([&](auto ch) {
             if constexpr (ch > 0) {
@@ -596,6 +641,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
             cb_wgrad<ALG>(A.w1[ch], Wq, Pq, AD);
         });
         stamp(9);
+        CB_MARK(9);
         // ---- d/d(input) = W1^T gy (gy read back from W)
         cb_get(Wq, AD, s);
         auto gx_of = [&](auto ch, f4 (&gx)[8]) {
@@ -603,80 +649,97 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
             for (int d = 0; d < D; ++d) gx[d] = f4{0.f, 0.f, 0.f, 0.f};
             cb_mix_t<ALG, GS1>(gx, s, ldst + TF::w1(0, 0, ch));
         };
+        const CmTile<MODE> Tc = T;
+        auto next_tile = [&]() {   // the next tile's rows leave in front of this tile's stores / atomics
+            T = Tn;
+            in.issue(io, T, q);
+            asm volatile("" ::: "memory");
+        };
         if constexpr (K > 0) {
             f4 gx[8];
             gx_of(IC<0>{}, gx);
-            if (T.valid) cm_store_piece(io.plw_g1 + (size_t)T.row * ROW + q * D, gx);
+            next_tile();
+            if (Tc.valid) cm_store_piece(io.plw_g1 + (size_t)Tc.row * ROW + q * D, gx);
         } else if constexpr (MODE == MODE_EDGE) {
+            if constexpr (NA > 0) {
+                if (io.gx[1]) {
+                    f4 gx[8];
+                    gx_of(IC<1>{}, gx);
+                    static_for<0, (NA + 3) / 4>([&](auto v) {
+                        if (Tc.valid && q + 4 * v < NA) {
+                            float* p = io.gx[1] + (size_t)Tc.i_perm * (NA * D) + (q + 4 * v) * D;
+                            cl_st4(p, f4{gx[0][int(v)], gx[1][int(v)], gx[2][int(v)], gx[3][int(v)]});
+                            cl_st4(p + 4, f4{gx[4][int(v)], gx[5][int(v)], gx[6][int(v)], gx[7][int(v)]});
+                        }
+                    });
+                }
+            }
             if (io.gx[0]) {
                 f4 gx[8];
                 gx_of(IC<0>{}, gx);
                 if (io.row_store) {
-                    if (T.valid) cm_store_piece(io.gx[0] + (size_t)T.lrow * ROW + q * D, gx);
+                    next_tile();
+                    if (Tc.valid) cm_store_piece(io.gx[0] + (size_t)Tc.lrow * ROW + q * D, gx);
                 } else {
                     float* sc = Pq;   // both slots: a 16 x (ROW + 4) staging tile
                     static_assert(kCmRows * SS <= 2 * kCbSlot, "the staging tile fits the two slots");
                     cb_sync();
                     cm_store_piece(sc + r * SS + q * D, gx);
                     cb_sync();
-                    cm_scatter<ROW, true>(sc, T.valid ? T.i_dst : -1, T.valid ? T.i_src : -1, io.gx[0], lane);
+                    next_tile();
+                    cm_scatter<ROW, true>(sc, Tc.valid ? Tc.i_dst : -1, Tc.valid ? Tc.i_src : -1, io.gx[0], lane);
                     cb_sync();
                 }
-            }
-            if constexpr (NA > 0) {
-                if (io.gx[1]) {
-                    f4 gx[8];
-                    gx_of(IC<1>{}, gx);
-                    static_for<0, (NA + 3) / 4>([&](auto v) {
-                        if (T.valid && q + 4 * v < NA) {
-                            float* p = io.gx[1] + (size_t)T.i_perm * (NA * D) + (q + 4 * v) * D;
-                            cl_st4(p, f4{gx[0][int(v)], gx[1][int(v)], gx[2][int(v)], gx[3][int(v)]});
-                            cl_st4(p + 4, f4{gx[4][int(v)], gx[5][int(v)], gx[6][int(v)], gx[7][int(v)]});
-                        }
-                    });
-                }
+            } else {
+                next_tile();
             }
         } else {
             if (io.gx[0]) {
                 f4 gx[8];
                 gx_of(IC<0>{}, gx);
-                if (T.valid) {
+                if (Tc.valid) {
                     if (io.resid_bwd) {
                         CmPiece res;
-                        res.load(io.gy + (size_t)T.row * ROW + q * D);
+                        res.load(io.gy + (size_t)Tc.row * ROW + q * D);
                         f4 rr[8];
                         cm_unpack(rr, res);
 #pragma unroll
                         for (int d = 0; d < D; ++d) gx[d] += rr[d];
                     }
-                    cm_store_piece(io.gx[0] + (size_t)T.row * ROW + q * D, gx);
+                    cm_store_piece(io.gx[0] + (size_t)Tc.row * ROW + q * D, gx);
                 }
             }
             if (io.gx[1]) {
                 f4 gx[8];
                 gx_of(IC<1>{}, gx);
 #pragma unroll
-                for (int d = 0; d < D; ++d) gx[d] *= T.scale;
-                if (T.valid) cm_store_piece(io.gx[1] + (size_t)T.row * ROW + q * D, gx);
+                for (int d = 0; d < D; ++d) gx[d] *= Tc.scale;
+                if (Tc.valid) cm_store_piece(io.gx[1] + (size_t)Tc.row * ROW + q * D, gx);
             }
             if constexpr (NA > 0) {
                 if (io.gx[2]) {
                     f4 gx[8];
                     gx_of(IC<2>{}, gx);
                     static_for<0, (NA + 3) / 4>([&](auto v) {
-                        if (T.valid && q + 4 * v < NA) {
-                            float* p = io.gx[2] + (size_t)T.row * (NA * D) + (q + 4 * v) * D;
+                        if (Tc.valid && q + 4 * v < NA) {
+                            float* p = io.gx[2] + (size_t)Tc.row * (NA * D) + (q + 4 * v) * D;
                             cl_st4(p, f4{gx[0][int(v)], gx[1][int(v)], gx[2][int(v)], gx[3][int(v)]});
                             cl_st4(p + 4, f4{gx[4][int(v)], gx[5][int(v)], gx[6][int(v)], gx[7][int(v)]});
                         }
                     });
                 }
             }
+            next_tile();
         }
         cb_sync();
+        tile = tile_next;
         stamp(10);
+        CB_MARK(10);
     }
 
+#ifdef CSMPN_STAMPS
+    stamp.acc[18 + (wave >> 2)] += __builtin_amdgcn_s_memtime() - kstart;   // duration of the tile loop: waves 0-3 | waves 4-7
+#endif
     // ---- end of the block: the waves add their sums into ONE image of the slice (wave order: deterministic), the
     // workgroup writes it out. The image lies over the waves' slots.
     __syncthreads();
@@ -718,13 +781,14 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, ClStamp& stam
     static_assert(PT::total % 4 == 0, "slice length");
     for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kCbWaves) cl_st4(part + e, cl_ld4(img + e));
     stamp(17);
+        CB_MARK(17);
 }
 
 template <class ALG, int C, int MODE, int NBLK, int NA>
 constexpr size_t cb_lds_bytes() {
     int tabs = CmTab<C, MODE, NA, 0>::total;
     if (NBLK > 1 && CmTab<C, MODE, NA, 1>::total > tabs) tabs = CmTab<C, MODE, NA, 1>::total;
-    return sizeof(float) * (tabs + kCbWaves * 2 * kCbSlot);
+    return sizeof(float) * (tabs + kCbWaves * 2 * kCbSlot + 4);   // + the tile counter
 }
 
 // The backward kernel: the blocks one after the other (last block first) in ONE launch, each with its own tables staged
@@ -742,18 +806,21 @@ __global__ void __launch_bounds__(64 * kCbWaves) cemlp_cmb_kernel(const DevCemlp
     ClStamp stamp(0);
     constexpr int tabs0 = CmTab<C, MODE, NA, 0>::total, tabs1 = NBLK > 1 ? CmTab<C, MODE, NA, 1>::total : 0;
     constexpr int tabs = tabs0 > tabs1 ? tabs0 : tabs1;
+    int* ctr = reinterpret_cast<int*>(smem + tabs + kCbWaves * 2 * kCbSlot);
     if constexpr (NBLK > 1) {
         cb_stage_block<ALG, C, CmTab<C, MODE, NA, 1>>(Cd.b[1], smem, threadIdx.x);
+        if (threadIdx.x == 0) *ctr = 0;
         __syncthreads();
         stamp(0);
-        cb_block<ALG, C, MODE, NBLK, NA, 1>(io, smem, smem + tabs, stamp);
+        cb_block<ALG, C, MODE, NBLK, NA, 1>(io, smem, smem + tabs, ctr, stamp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
-        __syncthreads();                                   // ... and every wave is done with block 1's tables
+        __syncthreads();                                   // ... every wave's have, and every wave is done with block 1's tables
     }
     cb_stage_block<ALG, C, CmTab<C, MODE, NA, 0>>(Cd.b[0], smem, threadIdx.x);
+    if (threadIdx.x == 0) *ctr = 0;
     __syncthreads();
     stamp(0);
-    cb_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, smem + tabs, stamp);
+    cb_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, smem + tabs, ctr, stamp);
     stamp.flush(io.stamps, threadIdx.x & 63);
 }
 

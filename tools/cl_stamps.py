@@ -19,6 +19,10 @@ BWD = ["setup(stage tables)", "loads(wait)", "r:W1 mix", "r:silu", "r:linR/L", "
 
 CM_FWD = ["setup(stage tables)", "loads(wait)", "W1 mix b0", "silu b0", "linR/L b0", "norm+gp b0", "layernorm b0", "", "W1 mix b1",
           "silu b1", "linR/L b1", "norm+gp b1", "layernorm b1", "", "issue next + store/scatter"]
+# channel-MFMA backward, parked form (cemlp_cmb.hpp, round 4)
+CMB_BWD = ["setup(stage tables)", "input loads + W1 mix", "r:silu, z->P, gout->W, linR/L, norm+gp", "b:layernorm (ggp->W)",
+           "b:wgrad WL (slots)", "b:gp+norm per channel", "b:WL^T, WR^T, wgrad WR, gz->W", "input again + W1 mix, x->P",
+           "b:silu in place (W)", "b:wgrad W1 (slots)", "b:W1^T + store/scatter", "", "", "", "", "", "", "end-of-block sums", "tile loop, waves 0-3 (x2: per wave)", "tile loop, waves 4-7 (x2: per wave)"]
 
 
 def main(workload="S1", family="cl"):
@@ -53,7 +57,7 @@ def main(workload="S1", family="cl"):
         v = st.cpu().tolist()
         waves, tot = v[24], sum(v[:24])
         print(f"== {name}: {waves} waves, {tot / max(waves,1) / 1e3:.1f} kcycles per wave")
-        names = (CM_FWD if family == "cm" else FWD) if name.endswith("fwd") else BWD
+        names = (CM_FWD if family == "cm" else FWD) if name.endswith("fwd") else (CMB_BWD if family == "cm" else BWD)
         for i, nm in enumerate(names):
             if v[i] and nm:
                 print(f"   {nm:24s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
