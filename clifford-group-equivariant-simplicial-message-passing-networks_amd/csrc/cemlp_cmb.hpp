@@ -740,15 +740,17 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
 #ifdef CSMPN_STAMPS
     stamp.acc[18 + (wave >> 2)] += __builtin_amdgcn_s_memtime() - kstart;   // duration of the tile loop: waves 0-3 | waves 4-7
 #endif
-    // ---- end of the block: the waves add their sums into ONE image of the slice (wave order: deterministic), the
-    // workgroup writes it out. The image lies over the waves' slots.
+    // ---- end of the block: waves 0-3 write their sums as four images of the slice (the slots of two waves hold one
+    // image; every element of the slice has exactly one writer per wave), waves 4-7 add theirs on top, all threads add the
+    // four images in a fixed order and write the workgroup's slice. Two rounds and three barriers (the first version had
+    // the eight waves add into ONE image one after the other: 18 % of a 3-tiles-per-wave launch).
     __syncthreads();
-    float* img = work;
-    static_assert(PT::total <= kCbWaves * 2 * kCbSlot, "the image fits the slots");
-    for (int e = threadIdx.x; e < PT::total; e += 64 * kCbWaves) img[e] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < kCbWaves; ++w) {
-        if (wave == w) {
+    constexpr int IMG = 4 * kCbSlot;
+    static_assert(PT::total <= IMG, "one image fits the slots of two waves");
+    float* img = work + (wave & 3) * IMG;
+    for (int round = 0; round < 2; ++round) {
+        if ((wave >> 2) == round) {
+            const bool add = round != 0;
             const int j = lane & 15, qq = lane >> 4;
             // weight tiles: D[i = 4 qq + v][j] = d/dW[orow(i)][first channel + orow(j)] (4 grades = one 16-byte vector)
             auto put_tile = [&](const f4 (&acc)[4], int base, int I, int coff, int width) {
@@ -757,7 +759,9 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         float* p0 = img + base + (TF::orow(4 * qq + v) * I + coff + c) * G;
-                        cl_st4(p0, cl_ld4(p0) + f4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]});
+                        const f4 val = f4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]};
+                        const f4 old = cl_ld4(p0);
+                        cl_st4(p0, add ? old + val : val);
                     }
                 }
             };
@@ -771,7 +775,11 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
             for (int g = 0; g < kCbGroups; ++g) {
                 int v, idx;
                 SM::decode(g, j, v, idx);
-                if (v >= 0) img[PT::pS + PT::off(idx) + (4 * v + qq) * PT::stride(idx)] += A.sm[g];
+                if (v >= 0) {
+                    float* p0 = img + PT::pS + PT::off(idx) + (4 * v + qq) * PT::stride(idx);
+                    const float old = *p0;
+                    *p0 = add ? old + A.sm[g] : A.sm[g];
+                }
             }
         }
         __syncthreads();
@@ -779,7 +787,8 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
     float* part = io.rl_partials + (K == 0 ? 0 : (size_t)kClSliceCap * ClPart<ALG, C, CmTab<C, MODE, NA, 0>::I>::total) +
                   (size_t)blockIdx.x * PT::total;
     static_assert(PT::total % 4 == 0, "slice length");
-    for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kCbWaves) cl_st4(part + e, cl_ld4(img + e));
+    for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kCbWaves)
+        cl_st4(part + e, (cl_ld4(work + e) + cl_ld4(work + IMG + e)) + (cl_ld4(work + 2 * IMG + e) + cl_ld4(work + 3 * IMG + e)));
     stamp(17);
         CB_MARK(17);
 }
