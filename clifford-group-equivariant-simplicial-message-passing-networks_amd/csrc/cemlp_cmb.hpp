@@ -65,10 +65,10 @@ CSMPN_DEV constexpr int cb_unit(int i, int k) { return (i & 3) * 16 + (i >> 3) *
 
 // parameters -> the block's LDS tables (once per workgroup): CmTab's entries, every entry in cb_unit order, then the
 // per-channel parameter rows [b1, bL, la, 0 | sa[4] | sb[4] | sigmoid(an)[4] | w[P]] (as cemlp_cm.hpp)
-template <class ALG, int C, class TB>
+template <class ALG, int C, class TB, int NT = 64 * kCbWaves>
 __device__ void cb_stage_block(const DevBlock& B, float* base, int tid) {
-    constexpr int G = ALG::G, P = ALG::P, MB = TB::MB, NCH = TB::NCH, NT = 64 * kCbWaves;
-    static_assert(G == 4 && MB == 1, "Cl(3,0)-shaped algebra, one channel group");
+    constexpr int G = ALG::G, P = ALG::P, MB = TB::MB, NCH = TB::NCH;
+    static_assert(G == 4, "Cl(3,0)-shaped algebra");
     constexpr int NE1 = TB::n1 / 4, NEC = TB::nc / 4, NE = NE1 + 2 * NEC, NIT = (NE + NT - 1) / NT;
     const float *pW1 = B.W1, *pWR = B.WR, *pWL = B.WL;
     const float* src[NIT][4];
@@ -80,19 +80,26 @@ __device__ void cb_stage_block(const DevBlock& B, float* base, int tid) {
         for (int v = 0; v < 4; ++v) src[it][v] = nullptr;
         const int lane = e & 63, l16 = lane & 15, q = lane >> 4;
         dst[it] = 4 * ((e >> 6) * 64 + cb_unit(l16, q));
-        const int o = TB::orow(l16);
-        if (e < NE1) {
+        if (e < NE1) {   // entry (g, m', chunk)
             int r = e >> 6;
-            const int ch = r % NCH, g = r / NCH;
+            const int ch = r % NCH;
+            r /= NCH;
+            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int c = TB::chan(ch, q, v);
                 if (c >= 0) src[it][v] = pW1 + ((o * TB::I + c) * G + g);
             }
-        } else if (e < NE) {
-            const int f = e - NE1, which = f / NEC, g = (f - which * NEC) >> 6;
+        } else if (e < NE) {   // entry (which, g, m', m)
+            int f = e - NE1;
+            const int which = f / NEC;
+            f -= which * NEC;
+            int r = f >> 6;
+            const int m = r % MB;
+            r /= MB;
+            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
 #pragma unroll
-            for (int v = 0; v < 4; ++v) src[it][v] = (which == 0 ? pWR : pWL) + ((o * C + 4 * v + q) * G + g);
+            for (int v = 0; v < 4; ++v) src[it][v] = (which == 0 ? pWR : pWL) + ((o * C + 16 * m + 4 * v + q) * G + g);
         }
     }
     f4 val[NIT];
@@ -294,9 +301,16 @@ struct CbCollect {
 
 // one channel: geometric product + normalisation backward (as cm_gp_bwd), the parameter gradients handed to `emit`
 // in the order [w 0..19 | an 0..3] as soon as they are final
-template <class ALG, class EMIT>
-CSMPN_DEV void cb_gp_bwd(const float (&ggp)[8], const float (&zf)[8], const float (&R)[8], float (&gz)[8], float (&gR)[8],
+template <class ALG, bool PIN = false, class EMIT>
+CSMPN_DEV void cb_gp_bwd(const float (&ggp_in)[8], const float (&zf_in)[8], const float (&R)[8], float (&gz)[8], float (&gR)[8],
                          const float* pp, EMIT&& emit) {
+    // PIN (cemlp_cmp.hpp, 512-register budget): the paths in program order - every path's operands pass through an empty asm
+    float ggp[8], zf[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { ggp[d] = ggp_in[d]; zf[d] = zf_in[d]; }
+    auto pin8 = [](float (&x)[8]) {
+        asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+    };
     constexpr int D = ALG::D, G = ALG::G, P = ALG::P;
     const f4 sgv = cl_ld4(pp + 12);
     float rf[D], invden[G], nu[G], qR[G];
@@ -322,6 +336,7 @@ CSMPN_DEV void cb_gp_bwd(const float (&ggp)[8], const float (&zf)[8], const floa
         constexpr int j0 = ALG::gstart(gj), nj = ALG::gsize(gj);
         constexpr int k0 = ALG::gstart(gk), nk = ALG::gsize(gk);
         const float w = pp[16 + p];
+        if constexpr (PIN) { pin8(ggp); pin8(rf); pin8(zf); pin8(gz); pin8(gr); }
         float U[ni], V[nk];
 #pragma unroll
         for (int t = 0; t < ni; ++t) U[t] = 0.f;
