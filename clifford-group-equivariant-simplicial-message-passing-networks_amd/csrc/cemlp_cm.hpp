@@ -39,18 +39,12 @@ constexpr int kCmFwdStageRows = 8;   // rows of the forward's scatter staging ti
 // Scheduling fence between the per-channel sections of the backward: left alone, the scheduler interleaves the four
 // channels of a lane for instruction-level parallelism and quadruples the live temporaries (2 KB of scratch per lane).
 #define CM_FENCE() __builtin_amdgcn_sched_barrier(0)
-// Compiler barrier between 16-byte vector stores into a staging buffer and the float reads of the same bytes (and back):
-// the two access types carry different type-based alias information, and the compiler did move the second half's
-// stores in front of the first half's reads (found by the 101-edge parity case). Costs no instruction.
-#define CM_LDS_ORDER() asm volatile("" ::: "memory")
-// Workgroups per CU the backward is compiled for. Measured (round 3): the live set of a backward tile is ~330 registers
-// (y, R, d/d(gp), d/dz: 128; weight-gradient tiles + parameter sums: 76; one channel's product backward: ~110-150), so
-// a 256-register build spills 1.8 KB per lane (S2 edge backward 10.9 ms); at 512 registers it still spills 0.6 KB and
-// takes 5.1 ms against 2.5 ms of the row-per-lane kernel. The backward is therefore NOT dispatched by default
-// (CSMPN_CM_BWD=1 selects it; parity-tested); DESIGN.md 4.1c.
-#ifndef CM_BWD_OCC
-#define CM_BWD_OCC 1
-#endif
+// Ordering point between LDS accesses of DIFFERENT lanes of one wave (a lane stores into the per-wave staging tile, another
+// lane reads those bytes): the LDS executes a wave's operations in issue order, so no wait is needed - but the compiler
+// sees each lane's own stores and loads as disjoint addresses and may move them across each other (it did move the second
+// half's stores in front of the first half's reads: found by the 101-edge parity case). A compiler barrier + the wave
+// barrier intrinsic (a scheduling barrier, no instruction) state the contract at every such hand-over.
+#define CM_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 #ifndef CM_FWD_OCC
 #define CM_FWD_OCC 3   // workgroups per CU the forward is compiled for (~160 registers, <= 53 KB of LDS)
 #endif
@@ -83,77 +77,55 @@ struct CmTab {
     static constexpr int total = par + C * kClParStride;
 };
 
-// parameters -> LDS tables of one block (once per workgroup). BWD: the transposed tables follow the forward ones
-// (entry (g, out chunk, m, lane)[v] = W[16 m + 4 v + q][channel of column l16 of the chunk]) and the parameters move
-// behind them.
-template <class ALG, int C, class TB, bool BWD = false>
-__device__ void cm_stage_block(const DevBlock& B, float* base, int tid) {
-    constexpr int G = ALG::G, P = ALG::P, MB = TB::MB, NCH = TB::NCH, NT = 64 * kCmWaves;
-    static_assert(G == 4, "Cl(3,0)-shaped algebra");
-    constexpr int NE1 = TB::n1 / 4, NEC = TB::nc / 4, NEF = NE1 + 2 * NEC, NE = BWD ? 2 * NEF : NEF, NIT = (NE + NT - 1) / NT;
-    constexpr int PAR = BWD ? 2 * TB::par : TB::par;
+// 16-byte unit of lane (l16, q)'s vector inside a table entry of 64 units: lane order for the forward kernels (SWZ = false);
+// the order that also serves the transposed reads of the backward kernels (SWZ = true, cemlp_cmb.hpp)
+template <bool SWZ>
+CSMPN_DEV constexpr int cm_unit(int i, int k) { return SWZ ? (i & 3) * 16 + (i >> 3) * 8 + k * 2 + ((i >> 2) & 1) : i + 16 * k; }
+
+// parameters -> LDS tables of one block (once per workgroup of NT threads). A work item is one (output channel o, slot)
+// pair: slot = (chunk, q, v) of the block's input for W1 / (m, q, v) for linear_right / left; the FOUR grades of its weight
+// are 16 contiguous bytes in the reference layout [o][c][g] - one coalesced 16-byte load (consecutive items = consecutive
+// input channels) and four 4-byte LDS stores, one per grade's table entry. (Round 3 staged one (entry, lane) vector per item from
+// four scalar loads strided by the row length: 40 k cycles per block for 32 channels, a third of an md17-sized launch.)
+// Then the per-channel parameter rows [b1, bL, la, 0 | sa[4] | sb[4] | sigmoid(an)[4] | w[P]] (as cemlp_cl.hpp).
+template <class ALG, int C, class TB, int NT, bool SWZ>
+__device__ void cm_stage_tables(const DevBlock& B, float* base, int tid) {
+    constexpr int G = ALG::G, P = ALG::P, MB = TB::MB, NCH = TB::NCH;
+    static_assert(G == 4, "Cl(3,0)-shaped algebra: the grades of one weight are one 16-byte vector");
+    constexpr int N1 = C * 16 * NCH, NC = C * C, NITEMS = N1 + 2 * NC, NIT = (NITEMS + NT - 1) / NT;
+    constexpr int GS1 = TB::w1(1, 0, 0) - TB::w1(0, 0, 0), GSC = TB::wc(0, 1, 0, 0) - TB::wc(0, 0, 0, 0);
     const float *pW1 = B.W1, *pWR = B.WR, *pWL = B.WL;
-    const float* src[NIT][4];
+    const float* src[NIT];
+    int dst[NIT], gs[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int e = tid + it * NT;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) src[it][v] = nullptr;
-        if (e < NE1) {
-            const int lane = e & 63, l16 = lane & 15, q = lane >> 4;
-            int r = e >> 6;
-            const int ch = r % NCH;
-            r /= NCH;
-            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = TB::chan(ch, q, v);
-                if (c >= 0) src[it][v] = pW1 + ((o * TB::I + c) * G + g);
-            }
-        } else if (e < NEF) {
-            int f = e - NE1;
-            const int which = f / NEC;
-            f -= which * NEC;
-            const int lane = f & 63, l16 = lane & 15, q = lane >> 4;
-            int r = f >> 6;
-            const int m = r % MB;
-            r /= MB;
-            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) src[it][v] = (which == 0 ? pWR : pWL) + ((o * C + 16 * m + 4 * v + q) * G + g);
-        } else if (e < NE) {
-            const int et = e - NEF;
-            if (et < NE1) {   // W1 transposed: [g][chunk][m][lane]
-                const int lane = et & 63, l16 = lane & 15, q = lane >> 4;
-                int r = et >> 6;
-                const int m = r % MB;
-                r /= MB;
-                const int ch = r % NCH, g = r / NCH;
-                const int c = TB::attr(ch) ? (TB::orow(l16) < TB::NA_ ? TB::NSEG * C + TB::orow(l16) : -1) : 16 * ch + TB::orow(l16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v)
-                    if (c >= 0) src[it][v] = pW1 + (((16 * m + 4 * v + q) * TB::I + c) * G + g);
-            } else {
-                int f = et - NE1;
-                const int which = f / NEC;
-                f -= which * NEC;
-                const int lane = f & 63, l16 = lane & 15, q = lane >> 4;
-                int r = f >> 6;
-                const int m = r % MB;
-                r /= MB;
-                const int mp = r % MB, g = r / MB, c = 16 * mp + TB::orow(l16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) src[it][v] = (which == 0 ? pWR : pWL) + (((16 * m + 4 * v + q) * C + c) * G + g);
-            }
+        src[it] = nullptr;
+        dst[it] = -1;
+        gs[it] = 0;
+        if (e < N1) {
+            const int o = e / (16 * NCH), cc = e % (16 * NCH), ch = cc >> 4, s16 = cc & 15;
+            const bool at = TB::attr(ch);
+            const int q = s16 & 3, v = s16 >> 2;          // full chunk: channel 16 ch + 4 v + q = 16 ch + s16; attributes: q + 4 v = s16
+            const int c = at ? (s16 < TB::NA_ ? TB::NSEG * C + s16 : -1) : 16 * ch + s16;
+            const int oo = o & 15, l16 = (oo >> 2) + 4 * (oo & 3);   // orow(l16) = oo
+            if (c >= 0) src[it] = pW1 + (size_t)(o * TB::I + c) * G;
+            dst[it] = TB::w1(0, o >> 4, ch) + 4 * cm_unit<SWZ>(l16, q) + v;
+            gs[it] = GS1;
+        } else if (e < NITEMS) {
+            int f = e - N1;
+            const int which = f / NC;
+            f -= which * NC;
+            const int o = f / C, c = f % C, m = c >> 4, s16 = c & 15, q = s16 & 3, v = s16 >> 2;
+            const int oo = o & 15, l16 = (oo >> 2) + 4 * (oo & 3);
+            src[it] = (which == 0 ? pWR : pWL) + (size_t)(o * C + c) * G;
+            dst[it] = TB::wc(which, 0, o >> 4, m) + 4 * cm_unit<SWZ>(l16, q) + v;
+            gs[it] = GSC;
         }
     }
     f4 val[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) val[it][v] = src[it][v] ? *src[it][v] : 0.f;
-    }
-    // per-channel parameters: [b1, bL, la, 0 | sa[4] | sb[4] | sigmoid(an)[4] | w[P]] per channel (as cemlp_cl.hpp)
+    for (int it = 0; it < NIT; ++it) val[it] = src[it] ? cl_ld4(src[it]) : f4{0.f, 0.f, 0.f, 0.f};
     constexpr int NPAR = C * kClParStride, NITP = (NPAR + NT - 1) / NT;
     static_assert(16 + P <= kClParStride, "parameter stride");
     const float *pb1 = B.b1, *pbL = B.bL, *pla = B.la, *psa = B.sa, *psb = B.sb, *pan = B.an, *pw = B.w;
@@ -181,15 +153,22 @@ __device__ void cm_stage_block(const DevBlock& B, float* base, int tid) {
     for (int it = 0; it < NITP; ++it) pv[it] = ps[it] ? *ps[it] : 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int e = tid + it * NT;
-        if (e < NE) cl_st4(base + 4 * e, val[it]);
+        if (dst[it] >= 0) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) base[dst[it] + g * gs[it]] = val[it][g];
+        }
     }
 #pragma unroll
     for (int it = 0; it < NITP; ++it) {
         const int e = tid + it * NT;
         if (sig[it]) pv[it] = sigmoidf(pv[it]);
-        if (e < NPAR) base[PAR + e] = pv[it];
+        if (e < NPAR) base[TB::par + e] = pv[it];
     }
+}
+// the forward's tables: lane order
+template <class ALG, int C, class TB>
+__device__ void cm_stage_block(const DevBlock& B, float* base, int tid) {
+    cm_stage_tables<ALG, C, TB, 64 * kCmWaves, false>(B, base, tid);
 }
 
 // acc[m'][d] += (one 16-slot chunk, NSTEP steps) x (its table entries). ldsa = LDS + 4 lane + the float offset of entry
@@ -596,19 +575,7 @@ constexpr size_t cm_fwd_lds_bytes() {
 }
 
 // =================================================================================
-// backward
-
-// float offsets of block K's tables in the backward (forward tables, their transposes, parameters)
-template <int C, int MODE, int NA, int K>
-struct CmTabB {
-    using F = CmTab<C, MODE, NA, K>;
-    static constexpr int MB = F::MB, NCH = F::NCH, ENT = F::ENT, I = F::I;
-    static constexpr int fwd = F::par;
-    static constexpr int w1t(int g, int ch, int m) { return fwd + ((g * NCH + ch) * MB + m) * ENT; }   // out chunk ch, in group m
-    static constexpr int wct(int which, int g, int mp, int m) { return fwd + F::n1 + which * F::nc + ((g * MB + mp) * MB + m) * ENT; }
-    static constexpr int par = 2 * F::par;
-    static constexpr int total = par + C * kClParStride;
-};
+// pieces of the backward shared by cemlp_cmb.hpp (16 channels, two waves per SIMD) and cemlp_cmp.hpp (32 channels, wave pairs)
 
 // acc[d] += (table entry of ONE (m', chunk) pair) x (the chunk's NSTEP steps). ldsa = LDS + 4 lane + offset of the pair's
 // grade-0 entry, GS = float stride between grades
@@ -640,81 +607,6 @@ CSMPN_DEV void cm_gate(const float (&y)[8], float (&gate)[4], const float* pp) {
             });
         }
         gate[g] = sigmoidf(__builtin_fmaf(sa[int(g)], u, sb[int(g)]));
-    });
-}
-
-// one channel: geometric product + normalisation backward. ggp = d/d(gp output) = d/d(linear_left output); zf = gate * y;
-// R = linear_right output. gz += d/dz through the product; gR = d/dR; gwa = {d/dw[0..P), d/d(an)[0..4)}.
-template <class ALG>
-CSMPN_DEV void cm_gp_bwd(const float (&ggp)[8], const float (&zf)[8], const float (&R)[8], float (&gz)[8], float (&gR)[8],
-                         float (&gwa)[ALG::P + 4], const float* pp) {
-    constexpr int D = ALG::D, G = ALG::G, P = ALG::P;
-    const f4 sgv = cl_ld4(pp + 12);
-    float rf[D], invden[G], nu[G], qR[G];
-    static_for<0, G>([&](auto g) {
-        constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-        float qq = 0.f;
-        static_for<0, nd>([&](auto t) {
-            constexpr int d = d0 + decltype(t)::value;
-            qq += qsf<ALG, d> * R[d] * R[d];
-        });
-        qR[g] = qq;
-        nu[g] = cl_smooth_abs_sqrt(qq);
-        invden[g] = fast_rcp(__builtin_fmaf(sgv[int(g)], nu[g] - 1.0f, 1.0f) + kEps);
-#pragma unroll
-        for (int t = 0; t < nd; ++t) rf[d0 + t] = R[d0 + t] * invden[g];
-    });
-    float gr[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) gr[d] = 0.f;
-    f4 wv[(P + 3) / 4];
-#pragma unroll
-    for (int q = 0; q < (P + 3) / 4; ++q) wv[q] = cl_ld4(pp + 16 + 4 * q);
-    static_for<0, P>([&](auto p) {
-        constexpr int gi = ALG::t.path_g[p][0], gj = ALG::t.path_g[p][1], gk = ALG::t.path_g[p][2];
-        constexpr int i0 = ALG::gstart(gi), ni = ALG::gsize(gi);
-        constexpr int j0 = ALG::gstart(gj), nj = ALG::gsize(gj);
-        constexpr int k0 = ALG::gstart(gk), nk = ALG::gsize(gk);
-        const float w = wv[p / 4][p % 4];
-        float U[ni], V[nk];
-#pragma unroll
-        for (int t = 0; t < ni; ++t) U[t] = 0.f;
-#pragma unroll
-        for (int t = 0; t < nk; ++t) V[t] = 0.f;
-        static_for<0, ni>([&](auto ii) {
-            static_for<0, nk>([&](auto kk) {
-                constexpr int i = i0 + ii, k = k0 + kk;
-                constexpr int j = ALG::t.out[i][k];
-                if constexpr (j >= j0 && j < j0 + nj) {
-                    constexpr float sg = float(ALG::t.sign[i][k]);
-                    U[ii] += (sg * ggp[j]) * rf[k];
-                    V[kk] += (sg * ggp[j]) * zf[i];
-                }
-            });
-        });
-        float gwv = 0.f;
-#pragma unroll
-        for (int t = 0; t < ni; ++t) { gz[i0 + t] = __builtin_fmaf(w, U[t], gz[i0 + t]); gwv = __builtin_fmaf(zf[i0 + t], U[t], gwv); }
-#pragma unroll
-        for (int t = 0; t < nk; ++t) gr[k0 + t] = __builtin_fmaf(w, V[t], gr[k0 + t]);
-        gwa[p] = gwv;
-    });
-    static_for<0, G>([&](auto g) {
-        constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-        float gden = 0.f;
-        static_for<0, nd>([&](auto t) {
-            constexpr int d = d0 + decltype(t)::value;
-            gden -= gr[d] * R[d];
-        });
-        gden *= invden[g] * invden[g];
-        const float sg = sgv[int(g)];
-        gwa[P + g] = gden * (nu[g] - 1.0f) * sg * (1.0f - sg);
-        const float inu = fast_rcp(nu[g]);
-        const float gq = (gden * sg) * (0.5f * qR[g]) * (inu * inu * inu);
-        static_for<0, nd>([&](auto t) {
-            constexpr int d = d0 + decltype(t)::value;
-            gR[d] = __builtin_fmaf(gr[d], invden[g], gq * (2.0f * qsf<ALG, d>) * R[d]);
-        });
     });
 }
 
@@ -753,450 +645,6 @@ CSMPN_DEV void cm_silu_bwd(const float (&gz)[8], const float (&y)[8], float (&gy
         });
     });
     gs[8] = gy[0];
-}
-
-// Sums over the 16 rows of the wave of NBF f4 values per lane (the per-channel parameter gradients): written [k][lane],
-// lane LANE0 + 4 k + q adds the 16 rows of (k, q) and accumulates them in acc (its running sum over the tiles of the launch).
-template <int NBF, int LANE0>
-CSMPN_DEV void cm_rows_sum(float* buf, const f4 (&val)[NBF], f4& acc, int lane) {
-    static_assert(NBF <= 8 && LANE0 + 4 * NBF <= 64, "one 8 KB buffer, one pass");
-#pragma unroll
-    for (int k = 0; k < NBF; ++k) cl_st4(buf + (k * 64 + lane) * 4, val[k]);
-    const int p = lane - LANE0;
-    const bool act = p >= 0 && p < 4 * NBF;
-    const int pc = act ? p : 0;
-    const float* src = buf + ((pc >> 2) * 64 + (pc & 3) * 16) * 4;
-    f4 s[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s[i] = cl_ld4(src + 4 * i);
-#pragma unroll
-    for (int r = 4; r < kCmRows; ++r) s[r & 3] += cl_ld4(src + 4 * r);
-    const f4 t = (s[0] + s[1]) + (s[2] + s[3]);
-    if (act) acc += t;
-}
-
-// transposition of four blades of a tensor through the wave's buffer: written [dd][row][4 q + v], read by lane (i, k) at
-// [dd][4 s + k][i] - the operand layout of an MFMA that contracts over rows (column i = channel 4 (i % 4) + i / 4)
-CSMPN_DEV void cm_tr_write(float* buf, const f4 (&t)[8], int half, int lane) {
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) cl_st4(buf + dd * 256 + (lane & 15) * 16 + 4 * (lane >> 4), t[4 * half + dd]);
-}
-// acc[g] += sum over the rows (and the blades of grade g) of a^T b; bufA / bufB: transposition buffers of 1024 floats
-template <class ALG, int HALF>
-CSMPN_DEV void cm_wgrad_half(f4 (&acc)[4], const float* bufA, const float* bufB, int lane) {
-    static_for<0, 4>([&](auto dd) {
-        constexpr int d = 4 * HALF + dd, g = ALG::grade(d);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[g] = mfma16(bufA[dd * 256 + 64 * s + lane], bufB[dd * 256 + 64 * s + lane], acc[g]);
-    });
-}
-
-// persistent sums of one wave over its tiles of one block
-template <int NCH>
-struct CmAcc {
-    f4 w1[NCH][4], wr[4], wl[4];   // weight-gradient tiles per grade: D[i][j] = d/dW[orow(i)][orow(j)]
-    f4 sm[3];                      // per-channel parameter sums (cm_rows_sum): lane L of sm[a] holds pair (pass, k, q)
-    CSMPN_DEV void zero() {
-        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            wr[g] = wl[g] = z;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) w1[c][g] = z;
-        }
-        sm[0] = sm[1] = sm[2] = z;
-    }
-};
-
-// backward of block K over this wave's tiles (C = 16). tab: the block's tables (CmTabB), work: per-wave scratch regions.
-template <class ALG, int C, int MODE, int NBLK, int NA, int K>
-__device__ void cm_bwd_block(const RowIO& io, float* tab, float* work, ClStamp& stamp) {
-    static_assert(C == 16, "one channel group (the transposition and the sum passes are laid out for MB = 1)");
-    using TF = CmTab<C, MODE, NA, K>;
-    using TB = CmTabB<C, MODE, NA, K>;
-    using PT = ClPart<ALG, C, TF::I>;
-    using RM = ClRed<ALG>;
-    constexpr int D = ALG::D, G = ALG::G, P = ALG::P, ROW = C * D, SS = ROW + 4, NCH = TF::NCH;
-    constexpr bool kLast = K == NBLK - 1;
-    constexpr int GS1 = TF::w1(1, 0, 0) - TF::w1(0, 0, 0), GSC = TF::wc(0, 1, 0, 0) - TF::wc(0, 0, 0, 0);
-    constexpr int GS1T = TB::w1t(1, 0, 0) - TB::w1t(0, 0, 0), GSCT = TB::wct(0, 1, 0, 0) - TB::wct(0, 0, 0, 0);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int r = lane & 15, q = lane >> 4;
-    float* sc = work + wave * (kCmRows * SS);   // staging tile / transposition buffers / sum passes
-    const float* ldsa = tab + 4 * lane;
-    const float* ldsp = tab + TB::par + kClParStride * q;
-    auto PP = [&](int v) { return ldsp + 4 * v * kClParStride; };
-
-    CmAcc<NCH> A;
-    A.zero();
-    const long ntiles = (io.rows + kCmRows - 1) / kCmRows;
-    const long tstride = (long)gridDim.x * kCmWaves;
-    for (long tile = (long)blockIdx.x * kCmWaves + wave; tile < ntiles; tile += tstride) {
-        asm volatile("" ::: "memory");   // the tables are loop invariant: keep their reads inside the loop (see the forward)
-        CmTile<MODE> T;
-        T.template load<NA>(io, tile, r);
-        // ---- loads: d/d(out) and the block's input
-        CmPiece gp;
-        {
-            const float* gsrc = (kLast ? io.gy + (size_t)(MODE == MODE_EDGE ? (long)T.i_dst : T.lrow) * ROW
-                                       : io.plw_g1 + (size_t)T.lrow * ROW) + q * D;
-            gp.load(gsrc);
-        }
-        f4 x[NCH][8];
-        auto load_x = [&]() {
-            if constexpr (K == 0) {
-                CmRaw<ALG, C, MODE, NA> raw;
-                raw.issue(io, T, q);
-                raw.template finish<TF>(x, T);
-            } else {
-                CmPiece sp;
-                sp.load(io.saved + (size_t)T.lrow * ROW + q * D);
-                cm_unpack(x[0], sp);
-            }
-        };
-        load_x();
-        stamp(1);
-        // ---- forward again: y (biased MVLinear output), R (linear_right output), s (block output in front of the norm)
-        f4 y[8], R[8], s[8];
-#pragma unroll
-        for (int d = 0; d < D; ++d) y[d] = R[d] = s[d] = f4{0.f, 0.f, 0.f, 0.f};
-        static_for<0, NCH>([&](auto ch) { cm_mix_one<ALG, TF::nstep(ch), GS1>(y, x[ch], ldsa + TF::w1(0, 0, ch)); });
-        float invMn;
-        {
-            f4 z[8];
-            static_for<0, 4>([&](auto v) {
-                float yy[D], zz[D], gate[4];
-#pragma unroll
-                for (int d = 0; d < D; ++d) yy[d] = y[d][int(v)];
-                cm_silu<ALG>(yy, zz, gate, PP(v));
-#pragma unroll
-                for (int d = 0; d < D; ++d) { y[d][int(v)] = yy[d]; z[d][int(v)] = zz[d]; }
-                CM_FENCE();
-            });
-            cm_mix_one<ALG, 4, GSC>(R, z, ldsa + TF::wc(0, 0, 0, 0));
-            cm_mix_one<ALG, 4, GSC>(s, z, ldsa + TF::wc(1, 0, 0, 0));
-            float nlsum = 0.f;
-            static_for<0, 4>([&](auto v) {
-                float zz[D], RR[D], LL[D], invden[4];
-#pragma unroll
-                for (int d = 0; d < D; ++d) { zz[d] = z[d][int(v)]; RR[d] = R[d][int(v)]; LL[d] = s[d][int(v)]; }
-                nlsum += cm_gp_tail<ALG>(zz, RR, LL, invden, PP(v));
-#pragma unroll
-                for (int d = 0; d < D; ++d) s[d][int(v)] = LL[d];
-                CM_FENCE();
-            });
-            invMn = fast_rcp(__builtin_fmaf(cm_q_sum(nlsum), 1.0f / float(C), kEps));
-        }
-        stamp(2);
-        // ---- MVLayerNorm backward: ggp = d/d(gp + linear_left output)
-        f4 ggp[8];
-        cm_unpack(ggp, gp);
-        if (!T.valid) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) ggp[d] = f4{0.f, 0.f, 0.f, 0.f};
-        }
-        {
-            float dot[4], S = 0.f;
-            static_for<0, 4>([&](auto v) {
-                float a = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) a = __builtin_fmaf(ggp[d][int(v)], s[d][int(v)], a);
-                dot[v] = a;
-                S = __builtin_fmaf(PP(v)[2], a, S);
-            });
-            const float gMn = -cm_q_sum(S) * invMn * invMn * (1.0f / float(C));
-            f4 sums[4];
-            static_for<0, 4>([&](auto v) {
-                float qs = 0.f;
-                static_for<0, D>([&](auto dd) {
-                    constexpr int d = decltype(dd)::value;
-                    qs += qsf<ALG, d> * s[d][int(v)] * s[d][int(v)];
-                });
-                const float inl = fast_rcp(cl_smooth_abs_sqrt(qs));
-                const float gqs = gMn * (0.5f * qs) * (inl * inl * inl);
-                const float k0 = PP(v)[2] * invMn;
-                static_for<0, D>([&](auto dd) {
-                    constexpr int d = decltype(dd)::value;
-                    const float gs = __builtin_fmaf(k0, ggp[d][int(v)], gqs * (2.0f * qsf<ALG, d>) * s[d][int(v)]);
-                    ggp[d][int(v)] = gs * kInvSqrt2;
-                });
-                sums[v] = f4{dot[v] * invMn, ggp[0][int(v)], 0.f, 0.f};   // d/d(la), d/d(bL)
-                CM_FENCE();
-            });
-            cm_rows_sum<4, 48>(sc, sums, A.sm[0], lane);
-        }
-        stamp(3);
-        // ---- d/d(linear_left weight) = ggp^T z, d/dz = WL^T ggp (+ the product's share below)
-        f4 gz[8];
-#pragma unroll
-        for (int d = 0; d < D; ++d) gz[d] = f4{0.f, 0.f, 0.f, 0.f};
-        {
-            f4 z[8];
-            static_for<0, 4>([&](auto v) {
-                float yy[D], gate[4];
-#pragma unroll
-                for (int d = 0; d < D; ++d) yy[d] = y[d][int(v)];
-                cm_gate<ALG>(yy, gate, PP(v));
-#pragma unroll
-                for (int d = 0; d < D; ++d) z[d][int(v)] = gate[ALG::grade(d)] * yy[d];
-                CM_FENCE();
-            });
-            static_for<0, 2>([&](auto half) {
-                CM_LDS_ORDER();
-                cm_tr_write(sc, ggp, half, lane);
-                cm_tr_write(sc + 1024, z, half, lane);
-                CM_LDS_ORDER();
-                cm_wgrad_half<ALG, half>(A.wl, sc, sc + 1024, lane);
-            });
-        }
-        cm_mix_one<ALG, 4, GSCT>(gz, ggp, ldsa + TB::wct(1, 0, 0, 0));
-        stamp(4);
-        // ---- geometric product + normalisation backward, per channel; R becomes d/dR
-        static_for<0, 4>([&](auto v) {
-            float yy[D], gate[4], zf[D], RR[D], gg[D], gzz[D], gRR[D], gwa[P + 4];
-#pragma unroll
-            for (int d = 0; d < D; ++d) { yy[d] = y[d][int(v)]; RR[d] = R[d][int(v)]; gg[d] = ggp[d][int(v)]; gzz[d] = gz[d][int(v)]; }
-            cm_gate<ALG>(yy, gate, PP(v));
-#pragma unroll
-            for (int d = 0; d < D; ++d) zf[d] = gate[ALG::grade(d)] * yy[d];
-            cm_gp_bwd<ALG>(gg, zf, RR, gzz, gRR, gwa, PP(v));
-#pragma unroll
-            for (int d = 0; d < D; ++d) { gz[d][int(v)] = gzz[d]; R[d][int(v)] = gRR[d]; }
-            static_assert(P == 20, "five f4 of path weights + one of normalisation parameters per channel");
-            f4 sums[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) sums[k] = f4{gwa[4 * k], gwa[4 * k + 1], gwa[4 * k + 2], gwa[4 * k + 3]};
-            // channels v = 0, 1 -> sm[0] lanes 0-23 / 24-47; v = 2, 3 -> sm[1]
-            cm_rows_sum<6, 24 * (v & 1)>(sc, sums, A.sm[v >> 1], lane);
-            CM_FENCE();
-        });
-        stamp(5);
-        // ---- d/d(linear_right weight) = gR^T z, d/dz += WR^T gR
-        {
-            f4 z[8];
-            static_for<0, 4>([&](auto v) {
-                float yy[D], gate[4];
-#pragma unroll
-                for (int d = 0; d < D; ++d) yy[d] = y[d][int(v)];
-                cm_gate<ALG>(yy, gate, PP(v));
-#pragma unroll
-                for (int d = 0; d < D; ++d) z[d][int(v)] = gate[ALG::grade(d)] * yy[d];
-                CM_FENCE();
-            });
-            static_for<0, 2>([&](auto half) {
-                CM_LDS_ORDER();
-                cm_tr_write(sc, R, half, lane);
-                cm_tr_write(sc + 1024, z, half, lane);
-                CM_LDS_ORDER();
-                cm_wgrad_half<ALG, half>(A.wr, sc, sc + 1024, lane);
-            });
-        }
-        cm_mix_one<ALG, 4, GSCT>(gz, R, ldsa + TB::wct(0, 0, 0, 0));
-        stamp(6);
-        // ---- MVSiLU backward: gz becomes d/dy
-        {
-            f4 sums[6];
-            static_for<0, 4>([&](auto v) {
-                float yy[D], gzz[D], gyy[D], gs[9];
-#pragma unroll
-                for (int d = 0; d < D; ++d) { yy[d] = y[d][int(v)]; gzz[d] = gz[d][int(v)]; }
-                cm_silu_bwd<ALG>(gzz, yy, gyy, gs, PP(v));
-#pragma unroll
-                for (int d = 0; d < D; ++d) gz[d][int(v)] = gyy[d];
-                constexpr int o = 3 * (v & 1);
-                sums[o] = f4{gs[0], gs[1], gs[2], gs[3]};
-                sums[o + 1] = f4{gs[4], gs[5], gs[6], gs[7]};
-                sums[o + 2] = f4{gs[8], 0.f, 0.f, 0.f};
-                // channels v = 0, 1 -> sm[2] lanes 0-23, v = 2, 3 -> lanes 24-47
-                if constexpr ((v & 1) == 1) cm_rows_sum<6, 24 * (v >> 1)>(sc, sums, A.sm[2], lane);
-                CM_FENCE();
-            });
-        }
-        stamp(7);
-        // ---- d/d(MVLinear weight) = gy^T x (the input again: asked for a second time through laundered indices - the
-        // compiler would otherwise keep the first copy alive across the whole tile), d/d(input) = W1^T gy
-        asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
-        load_x();
-        static_for<0, 2>([&](auto half) {
-            CM_LDS_ORDER();
-            cm_tr_write(sc, gz, half, lane);
-            static_for<0, NCH>([&](auto ch) {
-                CM_LDS_ORDER();
-                cm_tr_write(sc + 1024, x[ch], half, lane);
-                CM_LDS_ORDER();
-                cm_wgrad_half<ALG, half>(A.w1[ch], sc, sc + 1024, lane);
-            });
-        });
-        stamp(8);
-        auto gx_of = [&](auto ch, f4 (&gx)[8]) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) gx[d] = f4{0.f, 0.f, 0.f, 0.f};
-            cm_mix_one<ALG, 4, GS1T>(gx, gz, ldsa + TB::w1t(0, ch, 0));
-        };
-        if constexpr (K > 0) {
-            f4 gx[8];
-            gx_of(IC<0>{}, gx);
-            if (T.valid) cm_store_piece(io.plw_g1 + (size_t)T.row * ROW + q * D, gx);
-        } else if constexpr (MODE == MODE_EDGE) {
-            if (io.gx[0]) {
-                f4 gx[8];
-                gx_of(IC<0>{}, gx);
-                if (io.row_store) {
-                    if (T.valid) cm_store_piece(io.gx[0] + (size_t)T.lrow * ROW + q * D, gx);
-                } else {
-                    CM_LDS_ORDER();
-                    cm_store_piece(sc + r * SS + q * D, gx);
-                    CM_LDS_ORDER();
-                    cm_scatter<ROW, true>(sc, T.valid ? T.i_dst : -1, T.valid ? T.i_src : -1, io.gx[0], lane);
-                }
-            }
-            if constexpr (NA > 0) {
-                if (io.gx[1]) {
-                    f4 gx[8];
-                    gx_of(IC<1>{}, gx);
-                    // slot (q, v) of the attribute chunk = attribute channel q + 4 v
-                    static_for<0, (NA + 3) / 4>([&](auto v) {
-                        if (T.valid && q + 4 * v < NA) {
-                            float* p = io.gx[1] + (size_t)T.i_perm * (NA * D) + (q + 4 * v) * D;
-                            cl_st4(p, f4{gx[0][int(v)], gx[1][int(v)], gx[2][int(v)], gx[3][int(v)]});
-                            cl_st4(p + 4, f4{gx[4][int(v)], gx[5][int(v)], gx[6][int(v)], gx[7][int(v)]});
-                        }
-                    });
-                }
-            }
-        } else {
-            if (io.gx[0]) {
-                f4 gx[8];
-                gx_of(IC<0>{}, gx);
-                if (T.valid) {
-                    if (io.resid_bwd) {
-                        CmPiece res;
-                        res.load(io.gy + (size_t)T.row * ROW + q * D);
-                        f4 rr[8];
-                        cm_unpack(rr, res);
-#pragma unroll
-                        for (int d = 0; d < D; ++d) gx[d] += rr[d];
-                    }
-                    cm_store_piece(io.gx[0] + (size_t)T.row * ROW + q * D, gx);
-                }
-            }
-            if (io.gx[1]) {
-                f4 gx[8];
-                gx_of(IC<1>{}, gx);
-#pragma unroll
-                for (int d = 0; d < D; ++d) gx[d] *= T.scale;
-                if (T.valid) cm_store_piece(io.gx[1] + (size_t)T.row * ROW + q * D, gx);
-            }
-            if constexpr (NA > 0) {
-                if (io.gx[2]) {
-                    f4 gx[8];
-                    gx_of(IC<2>{}, gx);
-                    static_for<0, (NA + 3) / 4>([&](auto v) {
-                        if (T.valid && q + 4 * v < NA) {
-                            float* p = io.gx[2] + (size_t)T.row * (NA * D) + (q + 4 * v) * D;
-                            cl_st4(p, f4{gx[0][int(v)], gx[1][int(v)], gx[2][int(v)], gx[3][int(v)]});
-                            cl_st4(p + 4, f4{gx[4][int(v)], gx[5][int(v)], gx[6][int(v)], gx[7][int(v)]});
-                        }
-                    });
-                }
-            }
-        }
-        stamp(9);
-    }
-
-    // ---- end of the block: the four waves add their sums into ONE image of the slice (wave order: deterministic), the
-    // workgroup writes it out. The image lies over the waves' scratch regions.
-    __syncthreads();
-    float* img = work;
-    static_assert(PT::total <= kCmWaves * kCmRows * SS, "the image fits the scratch regions");
-    for (int e = threadIdx.x; e < PT::total; e += 64 * kCmWaves) img[e] = 0.f;
-    __syncthreads();
-    for (int w = 0; w < kCmWaves; ++w) {
-        if (wave == w) {
-            const int j = lane & 15, qq = lane >> 4;
-            // weight tiles: D[i = 4 qq + v][j] = d/dW[orow(i)][first channel + orow(j)] (4 grades = one 16-byte vector)
-            auto put_tile = [&](const f4 (&acc)[4], int base, int I, int coff, int width) {
-                const int c = TF::orow(j);
-                if (c < width) {
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        float* p0 = img + base + (TF::orow(4 * qq + v) * I + coff + c) * G;
-                        cl_st4(p0, cl_ld4(p0) + f4{acc[0][v], acc[1][v], acc[2][v], acc[3][v]});
-                    }
-                }
-            };
-            static_for<0, NCH>([&](auto ch) {
-                constexpr bool at = TF::attr(ch);
-                put_tile(A.w1[ch], 0, TF::I, at ? TF::NSEG * C : 16 * ch, at ? NA : 16);
-            });
-            put_tile(A.wr, PT::pWR, C, 0, C);
-            put_tile(A.wl, PT::pWL, C, 0, C);
-            // per-channel sums: lane L of sm[a] = (first ClRed index, count, channel)
-            auto put_small = [&](const f4& v, int idx0, int n, int chn) {
-                for (int e = 0; e < n; ++e) img[PT::pS + PT::off(idx0 + e) + chn * PT::stride(idx0 + e)] += v[e];
-            };
-            {   // sm[0]: lanes 0-23 channel q (v = 0), 24-47 channel 4 + q (v = 1): k = 0..4 path weights, 5 normalisation; 48-63: (la, bL) of channel 4 k + q
-                if (lane < 48) {
-                    const int v = lane / 24, p = lane % 24, k = p >> 2, cq = p & 3;
-                    put_small(A.sm[0], k < 5 ? RM::i_w + 4 * k : RM::i_an, 4, 4 * v + cq);
-                } else {
-                    const int p = lane - 48, k = p >> 2, cq = p & 3;
-                    put_small(A.sm[0], RM::i_la, 2, 4 * k + cq);
-                }
-                if (lane < 48) {   // sm[1]: channels v = 2, 3
-                    const int v = 2 + lane / 24, p = lane % 24, k = p >> 2, cq = p & 3;
-                    put_small(A.sm[1], k < 5 ? RM::i_w + 4 * k : RM::i_an, 4, 4 * v + cq);
-                    // sm[2]: lanes 0-23: channels v = 0, 1 (k = 3 (v & 1) + {0, 1, 2}), lanes 24-47: v = 2, 3
-                    const int vv = 2 * (lane / 24) + (k >= 3 ? 1 : 0), kk = k % 3;
-                    put_small(A.sm[2], kk < 2 ? RM::i_sa + 4 * kk : RM::i_b1, kk < 2 ? 4 : 1, 4 * vv + cq);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    float* part = io.rl_partials + (K == 0 ? 0 : (size_t)kClSliceCap * ClPart<ALG, C, CmTab<C, MODE, NA, 0>::I>::total) +
-                  (size_t)blockIdx.x * PT::total;
-    static_assert(PT::total % 4 == 0, "slice length");
-    for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kCmWaves) cl_st4(part + e, cl_ld4(img + e));
-    stamp(17);
-}
-
-template <class ALG, int C, int MODE, int NBLK, int NA>
-constexpr size_t cm_bwd_lds_bytes() {
-    int tabs = CmTabB<C, MODE, NA, 0>::total;
-    if (NBLK > 1 && CmTabB<C, MODE, NA, 1>::total > tabs) tabs = CmTabB<C, MODE, NA, 1>::total;
-    return sizeof(float) * (tabs + kCmWaves * kCmRows * (C * ALG::D + 4));
-}
-
-// The backward kernel: the blocks one after the other (last block first) in ONE launch, each with its own tables staged
-// in front of it (both blocks' tables + the waves' scratch would leave room for one workgroup per CU only). A wave
-// keeps its tiles from block to block: the hand-over rows d/d(block input) it reads in block k - 1 are the ones it
-// wrote itself in block k (through L2; drained before the barrier) - no grid-wide synchronisation.
-template <class ALG, int C, int MODE, int NBLK, int NA>
-__global__ void __launch_bounds__(64 * kCmWaves, CM_BWD_OCC) cemlp_cm_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
-    typedef const char __attribute__((address_space(4))) * KArgPtr;
-    const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
-    const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
-    const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
-    (void)C_arg; (void)io_arg;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    ClStamp stamp(0);
-    constexpr int tabs0 = CmTabB<C, MODE, NA, 0>::total, tabs1 = NBLK > 1 ? CmTabB<C, MODE, NA, 1>::total : 0;
-    constexpr int tabs = tabs0 > tabs1 ? tabs0 : tabs1;
-    if constexpr (NBLK > 1) {
-        cm_stage_block<ALG, C, CmTab<C, MODE, NA, 1>, true>(Cd.b[1], smem, threadIdx.x);
-        __syncthreads();
-        stamp(0);
-        cm_bwd_block<ALG, C, MODE, NBLK, NA, 1>(io, smem, smem + tabs, stamp);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
-        __syncthreads();                                   // ... and every wave is done with block 1's tables
-    }
-    cm_stage_block<ALG, C, CmTab<C, MODE, NA, 0>, true>(Cd.b[0], smem, threadIdx.x);
-    __syncthreads();
-    stamp(0);
-    cm_bwd_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, smem + tabs, stamp);
-    stamp.flush(io.stamps, threadIdx.x & 63);
 }
 
 }  // namespace csmpn

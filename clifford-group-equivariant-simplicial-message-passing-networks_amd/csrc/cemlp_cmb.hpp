@@ -61,88 +61,13 @@ CSMPN_DEV void cb_sync() {
 }
 
 // 16-byte unit of lane (i, k)'s vector inside a table entry of 64 units
-CSMPN_DEV constexpr int cb_unit(int i, int k) { return (i & 3) * 16 + (i >> 3) * 8 + k * 2 + ((i >> 2) & 1); }
+CSMPN_DEV constexpr int cb_unit(int i, int k) { return cm_unit<true>(i, k); }
 
 // parameters -> the block's LDS tables (once per workgroup): CmTab's entries, every entry in cb_unit order, then the
-// per-channel parameter rows [b1, bL, la, 0 | sa[4] | sb[4] | sigmoid(an)[4] | w[P]] (as cemlp_cm.hpp)
+// per-channel parameter rows (cm_stage_tables, cemlp_cm.hpp)
 template <class ALG, int C, class TB, int NT = 64 * kCbWaves>
 __device__ void cb_stage_block(const DevBlock& B, float* base, int tid) {
-    constexpr int G = ALG::G, P = ALG::P, MB = TB::MB, NCH = TB::NCH;
-    static_assert(G == 4, "Cl(3,0)-shaped algebra");
-    constexpr int NE1 = TB::n1 / 4, NEC = TB::nc / 4, NE = NE1 + 2 * NEC, NIT = (NE + NT - 1) / NT;
-    const float *pW1 = B.W1, *pWR = B.WR, *pWL = B.WL;
-    const float* src[NIT][4];
-    int dst[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int e = tid + it * NT;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) src[it][v] = nullptr;
-        const int lane = e & 63, l16 = lane & 15, q = lane >> 4;
-        dst[it] = 4 * ((e >> 6) * 64 + cb_unit(l16, q));
-        if (e < NE1) {   // entry (g, m', chunk)
-            int r = e >> 6;
-            const int ch = r % NCH;
-            r /= NCH;
-            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = TB::chan(ch, q, v);
-                if (c >= 0) src[it][v] = pW1 + ((o * TB::I + c) * G + g);
-            }
-        } else if (e < NE) {   // entry (which, g, m', m)
-            int f = e - NE1;
-            const int which = f / NEC;
-            f -= which * NEC;
-            int r = f >> 6;
-            const int m = r % MB;
-            r /= MB;
-            const int mp = r % MB, g = r / MB, o = 16 * mp + TB::orow(l16);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) src[it][v] = (which == 0 ? pWR : pWL) + ((o * C + 16 * m + 4 * v + q) * G + g);
-        }
-    }
-    f4 val[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) val[it][v] = src[it][v] ? *src[it][v] : 0.f;
-    }
-    constexpr int NPAR = C * kClParStride, NITP = (NPAR + NT - 1) / NT;
-    static_assert(16 + P <= kClParStride, "parameter stride");
-    const float *pb1 = B.b1, *pbL = B.bL, *pla = B.la, *psa = B.sa, *psb = B.sb, *pan = B.an, *pw = B.w;
-    const bool has_b1 = B.has_b1 != 0;
-    const float* ps[NITP];
-    bool sig[NITP];
-#pragma unroll
-    for (int it = 0; it < NITP; ++it) {
-        const int e = tid + it * NT;
-        ps[it] = nullptr;
-        sig[it] = false;
-        if (e < NPAR) {
-            const int ch = e / kClParStride, s = e % kClParStride;
-            if (s == 0) { if (has_b1) ps[it] = pb1 + ch; }
-            else if (s == 1) ps[it] = pbL + ch;
-            else if (s == 2) ps[it] = pla + ch;
-            else if (s >= 4 && s < 8) ps[it] = psa + ch * G + (s - 4);
-            else if (s >= 8 && s < 12) ps[it] = psb + ch * G + (s - 8);
-            else if (s >= 12 && s < 16) { ps[it] = pan + ch * G + (s - 12); sig[it] = true; }
-            else if (s >= 16 && s < 16 + P) ps[it] = pw + ch * P + (s - 16);
-        }
-    }
-    float pv[NITP];
-#pragma unroll
-    for (int it = 0; it < NITP; ++it) pv[it] = ps[it] ? *ps[it] : 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        if (tid + it * NT < NE) cl_st4(base + dst[it], val[it]);
-    }
-#pragma unroll
-    for (int it = 0; it < NITP; ++it) {
-        const int e = tid + it * NT;
-        if (sig[it]) pv[it] = sigmoidf(pv[it]);
-        if (e < NPAR) base[TB::par + e] = pv[it];
-    }
+    cm_stage_tables<ALG, C, TB, NT, true>(B, base, tid);
 }
 
 // float offsets of this lane inside a tensor slot (see the header): wr[v] - its own element (blade 0) of channel slot v;

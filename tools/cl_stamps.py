@@ -23,6 +23,10 @@ CM_FWD = ["setup(stage tables)", "loads(wait)", "W1 mix b0", "silu b0", "linR/L 
 CMB_BWD = ["setup(stage tables)", "input loads + W1 mix", "r:silu, z->P, gout->W, linR/L, norm+gp", "b:layernorm (ggp->W)",
            "b:wgrad WL (slots)", "b:gp+norm per channel", "b:WL^T, WR^T, wgrad WR, gz->W", "input again + W1 mix, x->P",
            "b:silu in place (W)", "b:wgrad W1 (slots)", "b:W1^T + store/scatter", "", "", "", "", "", "", "end-of-block sums", "tile loop, waves 0-3 (x2: per wave)", "tile loop, waves 4-7 (x2: per wave)"]
+# pair backward of the 32-channel layers (cemlp_cmp.hpp, round 4)
+CMP_BWD = ["setup(stage tables)", "input -> slots, W1 mix", "r:silu, z->slots, linR/L, gout load, norm+gp, row sums", "b:layernorm, ggp->slots",
+           "b:wgrad WL, WL^T", "b:gp+norm per channel", "b:gR->slots, input again, wgrad WR, WR^T", "input -> slots, W1 mix (y again)",
+           "b:silu, gy->slots, wgrad W1, W1^T", "", "next tile + store/scatter", "", "", "", "", "", "", "end-of-block sums"]
 
 
 def main(workload="S1", family="cl"):
@@ -57,7 +61,7 @@ def main(workload="S1", family="cl"):
         v = st.cpu().tolist()
         waves, tot = v[24], sum(v[:24])
         print(f"== {name}: {waves} waves, {tot / max(waves,1) / 1e3:.1f} kcycles per wave")
-        names = (CM_FWD if family == "cm" else FWD) if name.endswith("fwd") else (CMB_BWD if family == "cm" else BWD)
+        names = (CM_FWD if family == "cm" else FWD) if name.endswith("fwd") else ((CMP_BWD if C == 32 else CMB_BWD) if family == "cm" else BWD)
         for i, nm in enumerate(names):
             if v[i] and nm:
                 print(f"   {nm:24s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
