@@ -65,7 +65,7 @@ def algorithmic_bytes(C, D, A=6, T=3):
 
 def kernel_of(stage, name):
     """Does the rocprofv3 kernel name belong to this stage? (MODE 1 = edge, 2 = node; last template
-    argument = backward.) cemlp_rl_kernel<Alg, NOG, MODE, NBLK, I0, BWD>, cemlp_pl_kernel<Alg, MODE, NBLK, I0, BWD>,
+    argument = backward.) cemlp_pl_kernel<Alg, MODE, NBLK, I0, BWD>,
     cemlp_kernel<Alg, MODE, ...>, cemlp_ps_kernel<Alg, MODE, BWD>."""
     import re
     # cemlp_cl_{fwd,bwd}_kernel / cemlp_cm_{fwd,bwd}_kernel<Alg, C, MODE, NBLK, NA> (round 3: all blocks of a backward in one launch)
@@ -73,34 +73,43 @@ def kernel_of(stage, name):
     if m:
         args = [a.strip() for a in m.group(2).split(",")]
         return args[1] == ("1" if stage.startswith("edge") else "2") and (m.group(1) == "bwd") == stage.endswith("bwd")
-    m = re.search(r"cemlp(_rl|_ps|_pl)?_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+    # round 4: cemlp_cmb_kernel / cemlp_cmp_kernel<Alg, C, MODE, NBLK, NA>: the channel-MFMA backward (16 / 32 channels)
+    m = re.search(r"cemlp_cm[bp]_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+    if m:
+        args = [a.strip() for a in m.group(1).split(",")]
+        return args[1] == ("1" if stage.startswith("edge") else "2") and stage.endswith("bwd")
+    m = re.search(r"cemlp(_ps|_pl)?_kernel<csmpn::Alg<[^>]*>, ([^>]*)>", name)
     if not m:
         return False
     args = [a.strip() for a in m.group(2).split(",")]
-    mode = args[1] if m.group(1) == "_rl" else args[0]
+    mode = args[0]
     return mode == ("1" if stage.startswith("edge") else "2") and args[-1] == ("true" if stage.endswith("bwd") else "false")
 
 
-def pmc_traffic(stage, workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of THIS
-    workload (separate --pmc passes, tools/profile_r02.sh -> profiles/r02_<workload>_pmc_summary.json):
+def pmc_traffic(stage, workload, kernel_name=None):
+    """(HBM bytes per launch of the dominant kernel, file it came from) from the committed rocprofv3 PMC summary of THIS
+    workload (separate --pmc passes, tools/profile_r04.sh -> profiles/r04_<workload>_pmc_summary.json):
     2 x FETCH_SIZE (gfx950 counts a wide coalesced read at half its bytes, MI355X_MICROARCH.md HBM
-    section) + WRITE_SIZE, KB -> B. None when no summary of this workload is committed (counters cannot
-    be read from inside the timed run)."""
+    section) + WRITE_SIZE, KB -> B. The entry must carry the name of the kernel this run DISPATCHED (csmpn_last_kernel):
+    a summary recorded for another kernel - a stale profile - gives None, not its number. None too when no summary of this
+    workload is committed (counters cannot be read from inside the timed run)."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload}_pmc_summary.json")))
     if not found:
-        return None
+        return None, None
+    norm = lambda n: n.replace("void ", "").split("(")[0].replace(" ", "")
     try:
         with open(found[-1]) as f:
             best = None
             for name, c in json.load(f).items():
+                if kernel_name is not None and norm(name) != norm(kernel_name):
+                    continue
                 if kernel_of(stage, name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                     t = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
                     best = t if best is None or t > best else best
-            return best
+            return best, (os.path.relpath(found[-1], ROOT) if best is not None else None)
     except OSError:
-        return None
+        return None, None
 
 
 def make_inputs(metric, C, N, E_total, lo, hi, device):
@@ -222,7 +231,7 @@ def main():
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     pkg = importlib.import_module(PKG)
-    from csmpn_hip import ops, sharded
+    from csmpn_hip import native, ops, sharded
     if args.deterministic:
         ops.set_deterministic(True)
 
@@ -365,7 +374,7 @@ def main():
             "edge_bwd": lambda: be.edge_backward(spec, csr, hd, ea, pe, g_agg, gh, False, st_e),
         }
         reps = max(10, min(args.steps, 50))
-        stage_ms = {}
+        stage_ms, stage_kernel = {}, {}
         for name, fn in stages.items():
             fn()
             torch.cuda.synchronize()
@@ -376,20 +385,22 @@ def main():
                 b.record()
             torch.cuda.synchronize()
             stage_ms[name] = statistics.median(a.elapsed_time(b) for a, b in evs)
+            stage_kernel[name] = native.lib().csmpn_last_kernel().decode()   # what the entry point dispatched
         ab = algorithmic_bytes(C, D)
         units = {"edge_fwd": E_per, "edge_bwd": E_per, "node_fwd": N, "node_bwd": N}
         dom = max(stage_ms, key=stage_ms.get)
         alg_bytes = ab[dom] * units[dom]
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
         bytes_per_edge = ab["edge_fwd"] + ab["edge_bwd"] + (N / E_per) * (ab["node_fwd"] + ab["node_bwd"])
-        traffic = pmc_traffic(dom, args.workload)
+        traffic, traffic_source = pmc_traffic(dom, args.workload, stage_kernel[dom])
         roofline = {
-            "bound": "hbm", "kernel": f"{dom} (cemlp_cl_*_kernel: Cl(3,0) 8 channels; cemlp_rl_kernel: Cl(3,0) 16 channels (backward; their forward: cemlp_cm_fwd_kernel); cemlp_pl_kernel: Cl(5,0)|Cl(4,1) 8 channels; else cemlp_kernel / cemlp_ps_kernel)",
+            "bound": "hbm", "kernel": stage_kernel[dom], "stage": dom,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             # `frac` prices the ALGORITHMIC bytes (no reuse assumed for the gathers); the counters see fewer
             # bytes because h is L2-resident: the same kernel time against the MEASURED traffic of the committed PMC summary
             "frac_of_measured_traffic": None if traffic is None else round(traffic / (stage_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "layer_bytes_per_edge": round(bytes_per_edge, 1),

@@ -51,6 +51,7 @@ EXPORTS = (
     "csmpn_readout_mse_forward",
     "csmpn_readout_mse_backward",
     "csmpn_last_error",
+    "csmpn_last_kernel",
     "csmpn_abi_version",
     "csmpn_build_target",
 )

@@ -14,7 +14,6 @@
 #include "capi_common.hpp"
 #include "cemlp_kernel.hpp"
 #include "launch.hpp"
-#include "rl_launch.hpp"
 #include "cl_launch.hpp"
 #include "cm_launch.hpp"
 #include "pl_launch.hpp"
@@ -34,6 +33,54 @@ int csmpn_fail(int code, const char* fmt, ...) {
 
 namespace {
 
+// Every environment switch of the library, read ONCE per process. They select kernel families for A/B measurements and
+// parity tests of the slower paths or bound a launch for experiments; none of them changes results beyond summation
+// order. Documented in INTEGRATION.md ("Debug switches").
+struct Switches {
+    bool no_cl;          // CSMPN_NO_CL=1       Cl(3,0) 8-channel layers leave the (row, channel)-per-lane kernels (cemlp_cl.hpp) for the general ones
+    bool no_cm;          // CSMPN_NO_CM=1       16 / 32-channel Cl(3,0) layers leave the channel-MFMA kernels (cemlp_cm*.hpp)
+    bool no_cm_bwd;      // CSMPN_NO_CM_BWD=1   ... their backward only (forward stays)
+    bool no_pl;          // CSMPN_NO_PL=1       8-channel Cl(5,0) / Cl(4,1) layers leave the parity-lane kernels (cemlp_pl.hpp)
+    bool no_plw;         // CSMPN_NO_PLW=1      wide Cl(5,0) / Cl(4,1) layers leave the wide parity-lane kernels (cemlp_plw.hpp)
+    bool plw8;           // CSMPN_PLW8=1        8 channels on the wide parity-lane kernels with one group
+    bool no_share;       // CSMPN_NO_SHARE=1    general kernels: z does not alias the input tile
+    bool no_phased;      // CSMPN_NO_PHASED=1   general kernels: backward of all blocks per tile instead of block by block
+    bool no_sliced;      // CSMPN_NO_SLICED_GRADS=1  general kernels: parameter-gradient atomics onto one copy
+    bool debug;          // CSMPN_DEBUG         one line per launch on stderr: family, mode, shape, grid
+    int force_ps;        // CSMPN_FORCE_PS=0|1  parity-split layout of the general kernels off / on (-1: by algebra)
+    int force_h;         // CSMPN_FORCE_H=1|2   row halves per tile of the general kernels (0: by row count)
+    int min_lds_tiles;   // CSMPN_MIN_LDS_TILES resident row tiles below which the general kernels leave the LDS variant
+    long phased_min_rows;   // CSMPN_PHASED_MIN_ROWS  rows from which the phased backward is taken (default 4096)
+    long cl_cap_fwd, cl_cap_bwd;   // CSMPN_CL_CAP_FWD / _BWD  fewer resident workgroups of the cl kernels (experiments)
+};
+// name of the kernel the calling thread dispatched last (csmpn_last_kernel)
+thread_local char g_last_kernel[192] = "";
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+const Switches& sw() {
+    static const Switches s = [] {
+        auto flag = [](const char* n) { const char* v = getenv(n); return v && atoi(v) != 0; };
+        auto num = [](const char* n, long d) { const char* v = getenv(n); return v ? atol(v) : d; };
+        Switches r;
+        r.no_cl = flag("CSMPN_NO_CL"); r.no_cm = flag("CSMPN_NO_CM"); r.no_cm_bwd = flag("CSMPN_NO_CM_BWD");
+        r.no_pl = flag("CSMPN_NO_PL"); r.no_plw = flag("CSMPN_NO_PLW"); r.plw8 = flag("CSMPN_PLW8");
+        r.no_share = flag("CSMPN_NO_SHARE"); r.no_phased = flag("CSMPN_NO_PHASED"); r.no_sliced = flag("CSMPN_NO_SLICED_GRADS");
+        r.debug = getenv("CSMPN_DEBUG") != nullptr;
+        r.force_ps = getenv("CSMPN_FORCE_PS") ? (atoi(getenv("CSMPN_FORCE_PS")) != 0) : -1;
+        r.force_h = getenv("CSMPN_FORCE_H") ? (atoi(getenv("CSMPN_FORCE_H")) == 2 ? 2 : 1) : 0;
+        r.min_lds_tiles = (int)num("CSMPN_MIN_LDS_TILES", 1);
+        r.phased_min_rows = num("CSMPN_PHASED_MIN_ROWS", 16L * 256);
+        r.cl_cap_fwd = num("CSMPN_CL_CAP_FWD", 0); r.cl_cap_bwd = num("CSMPN_CL_CAP_BWD", 0);
+        return r;
+    }();
+    return s;
+}
+
+
 #define fail csmpn_fail
 
 #define HIP_TRY(expr)                                                                         \
@@ -47,6 +94,17 @@ inline int rup(int a, int b) { return cdiv(a, b) * b; }
 
 // ----------------------------------------------------------------------------- algebra id
 enum AlgId { ALG_NONE = -1, ALG_N2, ALG_N3, ALG_N4, ALG_N5, ALG_N5M, ALG_N4M };
+const char* alg_name(AlgId id) {
+    switch (id) {
+        case ALG_N2: return "csmpn::Alg<2, 0u>";
+        case ALG_N3: return "csmpn::Alg<3, 0u>";
+        case ALG_N4: return "csmpn::Alg<4, 0u>";
+        case ALG_N4M: return "csmpn::Alg<4, 8u>";
+        case ALG_N5: return "csmpn::Alg<5, 0u>";
+        case ALG_N5M: return "csmpn::Alg<5, 16u>";
+        default: return "csmpn::Alg<?>";
+    }
+}
 
 AlgId alg_id(const float* metric, int n) {
     if (!metric || n < 2 || n > 5) return ALG_NONE;
@@ -259,7 +317,7 @@ Choice choose_variant(int MT, size_t tile_bytes, size_t mirror_bytes, size_t wst
     };
     Choice c{VAR_GLOBAL, 1, 1, false};
     int rt = 0, wgs = 1;
-    static const int min_lds_waves = getenv("CSMPN_MIN_LDS_TILES") ? atoi(getenv("CSMPN_MIN_LDS_TILES")) : 1;
+    const int min_lds_waves = sw().min_lds_tiles;
     // single-wave tiles with gradient mirror and weight store in LDS
     if (MT == 1 && fit(mirror_bytes + wstore_bytes, rt, wgs) && rt * wgs >= min_lds_waves) {
         c.var = VAR_WAVE; c.rt = rt; c.wgs = wgs; c.mirror = bwd && mirror_bytes > 0;
@@ -323,8 +381,7 @@ bool decide_ps(AlgId id, int n, const csmpn_block_params* blocks, int nblk) {
     // Default: on for D = 32 (n = 5: half the registers per tensor and every lane column in use
     // instead of 8 of 16 - S3 runs 1.9x faster), off for Cl(3,0), where it measured 15-20 % slower
     // than the 32-row layout. CSMPN_FORCE_PS=0|1 overrides.
-    const char* f = getenv("CSMPN_FORCE_PS");
-    if (f ? atoi(f) == 0 : n < 5) return false;
+    if (sw().force_ps >= 0 ? sw().force_ps == 0 : n < 5) return false;
     for (int k = 0; k < nblk; ++k) if (blocks[k].out_features > 8) return false;
     const int D = 1 << n, G = n + 1;
     const size_t mirror = (size_t)mirror_total(G, n_paths(id), blocks, nblk) * 4;
@@ -351,7 +408,7 @@ int decide_h(AlgId id, int n, const csmpn_block_params* blocks, int nblk, bool b
     if (c2.var != VAR_WAVE || c2.rt * c2.wgs < 2) return 1;
     // 32-row tiles only when there are enough of them to occupy every wave slot of the chip;
     // small row counts (e.g. the node update of a 10k-node complex) get 16-row tiles
-    if (const char* f = getenv("CSMPN_FORCE_H")) return atoi(f) == 2 ? 2 : 1;   // debugging aid
+    if (sw().force_h) return sw().force_h;   // debugging aid
     const long tiles2 = (rows + 31) / 32;
     if (tiles2 < 256L * c2.rt * c2.wgs) return 1;
     return 2;
@@ -451,7 +508,7 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     // per CU (S2: 3 -> 4 waves per CU) or a better storage variant. Needs every block's input to be
     // re-stageable from memory: a single block, or saved block inputs.
     C.share_inz = 0;
-    static const bool allow_share = !(getenv("CSMPN_NO_SHARE") && atoi(getenv("CSMPN_NO_SHARE")));
+    const bool allow_share = !sw().no_share;
     if (bwd && !ps && H == 1 && allow_share && (use_saved || nblk == 1)) {
         const TileLayout Ls = tile_layout(D, H, blocks, nblk, bwd, stage_rowlen, use_saved, ps, true);
         const Choice cs = choose_variant(MT, (size_t)Ls.total * 4, (size_t)mirror * 4, (size_t)wstore * 4, bwd, ps);
@@ -467,11 +524,11 @@ int make_plan(AlgId id, int n, const csmpn_block_params* blocks, const csmpn_blo
     // Needs the saved block inputs and the hand-over region behind them (general_phased_shape: the same predicate sizes it).
     C.phased = 0;
     int mirror_used = mirror;
-    static const bool no_phased = getenv("CSMPN_NO_PHASED") && atoi(getenv("CSMPN_NO_PHASED"));
+    const bool no_phased = sw().no_phased;
     // Only where the all-blocks form already keeps a mirror (never away from the no-mirror variant: switching the md17 task
     // model's small node stages to the mirror form cost 6 % of its step) and for launches of at least one row tile per CU
     // (measured on the md17 model, 11 266 adjacencies: step 4.62 ms with a 32 k-row threshold, 4.47 ms with 4 k or 8 k).
-    static const long phased_min_rows = getenv("CSMPN_PHASED_MIN_ROWS") ? atol(getenv("CSMPN_PHASED_MIN_ROWS")) : 16L * 256;
+    const long phased_min_rows = sw().phased_min_rows;
     // From the no-mirror variant (per-tile float atomics onto the workgroup's copy) to the phased mirror form only for larger
     // launches (M32 node stage, 10 k rows: 0.59 -> 0.48 ms; the md17 model's 940-row node stages lose).
     const bool from_nm = ch.var == VAR_GROUP_NM && rows >= 2 * phased_min_rows;
@@ -577,35 +634,32 @@ int run_pack(const Plan& plan, hipStream_t st) {
 
 unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of cycle accumulators
 
-// bytes of the row-per-lane backward's partial buffer (one slice of parameter-gradient sums per
-// workgroup), reserved at the END of the workspace; 0 when the shape is not served by those kernels
+// bytes of the lane kernels' partial buffer (one slice of parameter-gradient sums per workgroup of a backward launch),
+// reserved at the END of the workspace; 0 when the shape is not served by those kernels
 size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 3 || nblk < 1 || nblk > 2) return 0;
     const int ch = blocks[0].out_features;
     for (int k = 0; k < nblk; ++k)
         if (blocks[k].out_features != ch || (k > 0 && blocks[k].in_features != ch)) return 0;
-    const size_t rl = cemlp_rl_partial_floats_n3(nblk, ch, blocks[0].in_features) * sizeof(float) * kRlPartialGroups;
-    // (row, channel)-per-lane backward (cemlp_cl.hpp): one slice per workgroup of a block launch; the same region
+    // (row, channel)-per-lane backward (cemlp_cl.hpp): one slice per workgroup
     const int i0 = blocks[0].in_features;
     size_t clf = cemlp_cl_partial_floats_n3(MODE_EDGE, nblk, ch, i0);
     const size_t cln = cemlp_cl_partial_floats_n3(MODE_NODE, nblk, ch, i0);
     clf = cln > clf ? cln : clf;
     size_t cl = clf * sizeof(float) * kClMaxBwdGroups;
-    // channel-MFMA backward (cemlp_cm.hpp): the same region and slice layout
+    // channel-MFMA backward (cemlp_cmb.hpp / cemlp_cmp.hpp): the same region and slice layout
     size_t cmf = cemlp_cm_partial_floats_n3(MODE_EDGE, nblk, ch, i0);
     const size_t cmn = cemlp_cm_partial_floats_n3(MODE_NODE, nblk, ch, i0);
     cmf = cmn > cmf ? cmn : cmf;
     const size_t cm = cmf * sizeof(float) * kCmSliceCap;
-    cl = cm > cl ? cm : cl;
-    return cl > rl ? cl : rl;
+    return cm > cl ? cm : cl;
 }
 // The channel-MFMA backward (cemlp_cmb.hpp, round 4: two waves per SIMD, tensors parked in LDS) serves the 16-channel
 // Cl(3,0) layers; CSMPN_NO_CM_BWD=1 leaves them to the row-per-lane backward (A/B measurements). Read ONCE per process: the
 // size of the saved region the caller allocates (csmpn_cemlp_saved_floats_per_row) depends on it and must not change
 // under a live plan.
 bool cm_bwd_enabled() {
-    static const bool on = !(getenv("CSMPN_NO_CM_BWD") && atoi(getenv("CSMPN_NO_CM_BWD")));
-    return on;
+    return !sw().no_cm_bwd;
 }
 // the (row, channel)-per-lane backward hands d/d(block-1 input) from its block-1 launch to its block-0 launch through
 // one more [rows, C, D] region behind the saved block inputs (as the wide parity-lane kernels do)
@@ -625,7 +679,6 @@ bool general_phased_shape(int n, const csmpn_block_params* blocks, int nblk) {
         const int ch = blocks[0].out_features, i0 = blocks[0].in_features;
         if (blocks[1].out_features == ch && blocks[1].in_features == ch) {
             if (cl_shape(n, blocks, nblk)) return false;
-            if (has_cemlp_rl_n3(MODE_EDGE, nblk, ch, i0) || has_cemlp_rl_n3(MODE_NODE, nblk, ch, i0)) return false;
         }
     }
     return true;
@@ -654,37 +707,10 @@ size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256 + plw_part_bytes(ch);
 }
 
-// Row-per-lane kernels (cemlp_rl.hpp): every block 8 channels wide, MVLinear with per-grade
-// weights, and (backward of a two-block CEMLP) the block-1 input saved by the forward.
-// CSMPN_NO_RL=1 keeps the generic kernels (A/B measurements, parity tests of both paths).
-bool rl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
-    static const bool off = getenv("CSMPN_NO_RL") && atoi(getenv("CSMPN_NO_RL"));
-    if (off || id != ALG_N3) return false;
-    const DevCemlp& C = plan.C;
-    if (C.nblk < 1 || C.nblk > 2) return false;
-    const int ch = C.b[0].O;
-    for (int k = 0; k < C.nblk; ++k) {
-        if (C.b[k].O != ch || !C.b[k].w1_sub) return false;
-        if (k > 0 && C.b[k].I != ch) return false;
-    }
-    if (mode == MODE_EDGE && io.seg[0].ch != ch) return false;
-    if (mode == MODE_NODE && (io.seg[0].ch != ch || io.seg[1].ch != ch)) return false;
-    if (bwd && C.nblk > 1 && !io.saved) return false;
-    *channels = ch;
-    *i0 = C.b[0].I;
-    if (!has_cemlp_rl_n3(mode, C.nblk, ch, C.b[0].I)) return false;
-    if (bwd) {
-        const size_t pb = cemlp_rl_partial_floats_n3(C.nblk, ch, C.b[0].I) * sizeof(float) * kRlPartialGroups;
-        if (!plan.workspace || plan.workspace_bytes < pb) return false;
-    }
-    return true;
-}
-
 // (row, channel)-per-lane kernels (cemlp_cl.hpp): Cl(3,0), two blocks of 8 channels, the EGCL attribute widths of S1.
 // CSMPN_NO_CL=1 leaves these shapes to the row-per-lane kernels (A/B measurements, parity tests of both paths).
 bool cl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
-    static const bool off = getenv("CSMPN_NO_CL") && atoi(getenv("CSMPN_NO_CL"));
-    if (off || id != ALG_N3) return false;
+    if (sw().no_cl || id != ALG_N3) return false;
     const DevCemlp& C = plan.C;
     if (C.nblk != 2) return false;
     const int ch = C.b[0].O;
@@ -710,8 +736,7 @@ bool cl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
 // attribute widths (6, 3).
 // CSMPN_NO_CM=1 leaves these shapes to the row-per-lane kernels (A/B measurements, parity tests of both paths).
 bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* i0) {
-    static const bool off = getenv("CSMPN_NO_CM") && atoi(getenv("CSMPN_NO_CM"));
-    if (off || id != ALG_N3) return false;
+    if (sw().no_cm || id != ALG_N3) return false;
     const DevCemlp& C = plan.C;
     if (C.nblk != 2) return false;
     const int ch = C.b[0].O;
@@ -736,8 +761,7 @@ bool cm_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
 
 // parity-lane kernels (cemlp_pl.hpp): Cl(5,0) / Cl(4,1), two blocks of 8 channels, the EGCL attribute widths of S3
 bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* i0) {
-    static const bool off = getenv("CSMPN_NO_PL") && atoi(getenv("CSMPN_NO_PL"));
-    if (off || (id != ALG_N5 && id != ALG_N5M)) return false;
+    if (sw().no_pl || (id != ALG_N5 && id != ALG_N5M)) return false;
     const DevCemlp& C = plan.C;
     if (C.nblk != 2) return false;
     for (int k = 0; k < C.nblk; ++k) {
@@ -754,12 +778,11 @@ bool pl_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
 
 // wide parity-lane kernels (cemlp_plw.hpp): Cl(5,0) / Cl(4,1), two blocks of 16 / 24 / 28 / 32 channels, EGCL edge / node programs
 bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
-    static const bool off = getenv("CSMPN_NO_PLW") && atoi(getenv("CSMPN_NO_PLW"));
-    if (off || (id != ALG_N5 && id != ALG_N5M)) return false;
+    if (sw().no_plw || (id != ALG_N5 && id != ALG_N5M)) return false;
     const DevCemlp& C = plan.C;
     if (C.nblk < 1 || C.nblk > 2) return false;
     const int ch = C.b[0].O;
-    static const bool plw8 = getenv("CSMPN_PLW8") && atoi(getenv("CSMPN_PLW8"));   // 8 channels: wide kernels with one group
+    const bool plw8 = sw().plw8;   // 8 channels: wide kernels with one group
     // 8 channels belong to cemlp_pl.hpp; the one-group wide kernels take them only on request (round 2 measured them 4-5x
     // slower - compiled for four waves per SIMD by mistake, 1.3 KB of scratch; with the launch bounds repaired they are on a
     // par: S3 1.339 against 1.333 ms)
@@ -803,11 +826,15 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - plw_part_bytes(channels));
             if (bwd && plan.C.nblk > 1) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // see csmpn_cemlp_saved_floats_per_row
             bool handled = false;
-            static const bool debug_plw = getenv("CSMPN_DEBUG") != nullptr;
+            const bool debug_plw = sw().debug;
             if (debug_plw) fprintf(stderr, "[csmpn] plw mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
             if (id == ALG_N5) HIP_TRY(launch_cemlp_plw_n5(mode, channels, attr, plan.C.nblk, bwd, grid, st, plan.C, io, tabs, &handled));
             else HIP_TRY(launch_cemlp_plw_n5m(mode, channels, attr, plan.C.nblk, bwd, grid, st, plan.C, io, tabs, &handled));
-            if (handled) return CSMPN_OK;
+            if (handled) {   // the wide kernels' template arguments live in plw_inst.inc: family + shape
+                note_kernel("csmpn::cemlp_plw_%s_kernel<%s, ...> (mode %d, %d channels, %d attribute channels, %d blocks)", bwd ? "bwd" : "fwd",
+                            alg_name(id), mode, channels, attr, plan.C.nblk);
+                return CSMPN_OK;
+            }
         }
     }
     {
@@ -823,11 +850,14 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
                 io.plw_part = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb - 16) & ~(size_t)255));
             }
             bool handled = false;
-            static const bool debug_pl = getenv("CSMPN_DEBUG") != nullptr;
+            const bool debug_pl = sw().debug;
             if (debug_pl) fprintf(stderr, "[csmpn] pl mode=%d bwd=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, i0, grid, io.rows);
             if (id == ALG_N5) HIP_TRY(launch_cemlp_pl_n5(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
             else HIP_TRY(launch_cemlp_pl_n5m(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
-            if (handled) return CSMPN_OK;
+            if (handled) {
+                note_kernel("csmpn::cemlp_pl_kernel<%s, %d, %d, %d, %s>", alg_name(id), mode, plan.C.nblk, i0, bwd ? "true" : "false");
+                return CSMPN_OK;
+            }
         }
     }
     {
@@ -839,8 +869,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             // block backward (<= 256)
             long cap = bwd ? kClMaxBwdGroups : kClMaxFwdGroups;
             // experiments: fewer resident workgroups (never more: the partial buffer has kClMaxBwdGroups slices)
-            static const long cap_f = getenv("CSMPN_CL_CAP_FWD") ? atol(getenv("CSMPN_CL_CAP_FWD")) : 0;
-            static const long cap_b = getenv("CSMPN_CL_CAP_BWD") ? atol(getenv("CSMPN_CL_CAP_BWD")) : 0;
+            const long cap_f = sw().cl_cap_fwd, cap_b = sw().cl_cap_bwd;
             if (!bwd && cap_f > 0 && cap_f < 4096) cap = cap_f;
             if (bwd && cap_b > 0 && cap_b < cap) cap = cap_b;
             const long groups = (tiles + 3) / 4;
@@ -851,10 +880,14 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
                 io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // see csmpn_cemlp_saved_floats_per_row
             }
             bool handled = false;
-            static const bool debug_cl = getenv("CSMPN_DEBUG") != nullptr;
+            const bool debug_cl = sw().debug;
             if (debug_cl) fprintf(stderr, "[csmpn] cl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
             HIP_TRY(launch_cemlp_cl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
-            if (handled) return CSMPN_OK;
+            if (handled) {
+                note_kernel("csmpn::cemlp_cl_%s_kernel<%s, %d, %d, %d, %d>", bwd ? "bwd" : "fwd", alg_name(id), channels, mode, plan.C.nblk,
+                            i0 - (mode == MODE_EDGE ? 1 : 2) * channels);
+                return CSMPN_OK;
+            }
         }
     }
     {
@@ -870,32 +903,14 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
                 io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // see csmpn_cemlp_saved_floats_per_row
             }
             bool handled = false;
-            static const bool debug_cm = getenv("CSMPN_DEBUG") != nullptr;
+            const bool debug_cm = sw().debug;
             if (debug_cm) fprintf(stderr, "[csmpn] cm mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
             HIP_TRY(launch_cemlp_cm_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
-            if (handled) return CSMPN_OK;
-        }
-    }
-    {
-        int channels = 0, i0 = 0;
-        if (rl_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
-            const long rows_per_wave = 64 / (channels / 4);
-            const long tiles = (io.rows + rows_per_wave - 1) / rows_per_wave;
-            // one 4-wave workgroup per CU in the backward (512 VGPRs), two in the forward; few tiles
-            // spread one per workgroup (wave 0) over the CUs first
-            // tile t belongs to wave t % 4 of workgroup (t / 4) % grid
-            const long cap = bwd ? kRlMaxBwdGroups : 512;
-            const long groups = (tiles + 3) / 4;
-            const unsigned grid = (unsigned)(groups < cap ? groups : cap);
-            if (bwd) {
-                const size_t pb = cemlp_rl_partial_floats_n3(plan.C.nblk, channels, i0) * sizeof(float) * kRlPartialGroups;
-                io.rl_partials = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb) & ~(size_t)15));
+            if (handled) {
+                note_kernel("csmpn::cemlp_%s_kernel<%s, %d, %d, %d, %d>", !bwd ? "cm_fwd" : (channels == 32 ? "cmp" : "cmb"), alg_name(id), channels,
+                            mode, plan.C.nblk, i0 - (mode == MODE_EDGE ? 1 : 2) * channels);
+                return CSMPN_OK;
             }
-            bool handled = false;
-            static const bool debug_rl = getenv("CSMPN_DEBUG") != nullptr;
-            if (debug_rl) fprintf(stderr, "[csmpn] rl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
-            HIP_TRY(launch_cemlp_rl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
-            if (handled) return CSMPN_OK;
         }
     }
     if (io.row_store && !plan.det_general)
@@ -910,7 +925,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     // Per-workgroup copies of the gradient tensors at the end of the workspace: always in deterministic mode, and (round 3)
     // for every backward of the small algebras - the parameter-gradient atomics of ALL row tiles onto one copy were the
     // bulk of the md17-width backward (M32 node stage 1.04 -> 0.53 ms with private copies); CSMPN_NO_SLICED_GRADS=1: off.
-    static const bool no_sliced = getenv("CSMPN_NO_SLICED_GRADS") && atoi(getenv("CSMPN_NO_SLICED_GRADS"));
+    const bool no_sliced = sw().no_sliced;
     const bool sliced = bwd && (io.row_store || (!no_sliced && (id == ALG_N2 || id == ALG_N3) && !plan.ps && plan.var != VAR_GLOBAL));
     if (sliced) {
         const int G = (id == ALG_N2) ? 3 : 4, P = n_paths(id);   // det_general: n <= 3
@@ -966,7 +981,7 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     long grid = (ntiles + Cd.RT - 1) / Cd.RT;
     if (grid > (long)plan.grid_cap) grid = plan.grid_cap;
     if (det_bytes && grid > kDetGroups) grid = kDetGroups;
-    static const bool debug = getenv("CSMPN_DEBUG") != nullptr;
+    const bool debug = sw().debug;
     if (debug)
         fprintf(stderr, "[csmpn] mode=%d bwd=%d var=%d ps=%d share=%d phased=%d H=%d MT=%d RT=%d threads=%u lds=%zu grid=%ld tile_floats=%d mirror=%d rows=%ld\n",
                 mode, (int)bwd, plan.var, (int)plan.ps, Cd.share_inz, (int)(bwd && Cd.phased), plan.H, Cd.MT, Cd.RT, threads, lds_bytes, grid,
@@ -991,6 +1006,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
     }
     if (plan.ps) HIP_TRY(launch_cemlp_ps(id, mode, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
     else HIP_TRY(launch_cemlp(id, mode, plan.var, plan.H, bwd, (unsigned)grid, threads, lds_bytes, st, Cd, io));
+    if (plan.ps) note_kernel("csmpn::cemlp_ps_kernel<%s, %d, %s>", alg_name(id), mode, bwd ? "true" : "false");
+    else note_kernel("csmpn::cemlp_kernel<%s, %d, %d, %d, %s>", alg_name(id), mode, plan.var, plan.H, bwd ? "true" : "false");
     if (det_bytes) {
         hipLaunchKernelGGL(det_reduce_kernel, dim3((det_total + 255) / 256), dim3(256), 0, st, det_map, (const float*)det_slices, (int)grid);
         HIP_TRY(hipGetLastError());
@@ -1098,6 +1115,7 @@ int mvlinear_desc(int n, long rows, int I, int O, int sub, MvLinDesc& P) {
 extern "C" {
 
 const char* csmpn_last_error(void) { return g_csmpn_err; }
+const char* csmpn_last_kernel(void) { return g_last_kernel; }
 
 /* diagnostic (-DCSMPN_STAMPS builds): device buffer of 25 uint64 per-phase cycle sums + wave count */
 void csmpn_debug_set_stamps(void* device_u64x25) { g_stamps = static_cast<unsigned long long*>(device_u64x25); }

@@ -309,6 +309,11 @@ int csmpn_readout_mse_backward(int n, const float* weight, int32_t weight_stride
 /* Last error message of the calling thread (never NULL). */
 const char* csmpn_last_error(void);
 
+/* Diagnostic: the kernel the calling thread's last CEMLP / EGCL-stage entry point dispatched ("" before the first
+ * launch), spelled as rocprofv3 prints it where the family's template arguments are known at the dispatch site, e.g.
+ * "csmpn::cemlp_cl_bwd_kernel<csmpn::Alg<3, 0u>, 8, 1, 2, 6>". bench.py reports it as roofline.kernel. */
+const char* csmpn_last_kernel(void);
+
 /* Library/ABI version and the gfx target it was built for. */
 int csmpn_abi_version(void);
 const char* csmpn_build_target(void);

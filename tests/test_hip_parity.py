@@ -393,20 +393,22 @@ def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
             _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=N + E, residual=residual, neg_scale=0.02, attr_grad=True, slack=4.0)
 
 
-def test_channel_mfma_backward_opt_in(pkg):
-    """The channel-MFMA backward (cemlp_cm.hpp; not dispatched by default - slower than the row-per-lane backward it would
-    replace) stays parity-green: the 16-channel Cl(3,0) shape cases again in a child process with CSMPN_CM_BWD=1 (the
-    switch is read once per process), and the library's dispatch log must show that kernel family taking the backward."""
+def test_channel_mfma_backward_dispatched(pkg):
+    """Round 4: the channel-MFMA backward (cemlp_cmb.hpp: 16 channels, two waves per SIMD; cemlp_cmp.hpp: 32 channels, wave
+    pairs) is the default of those widths: the shape cases again in a child process with the dispatch log on - the log must
+    show that kernel family taking both backward stages."""
     import subprocess
-    env = dict(os.environ, CSMPN_CM_BWD="1", CSMPN_DEBUG="1")
+    env = dict(os.environ, CSMPN_DEBUG="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-m", "gpu", "-x", "-k",
-                        "test_lane_kernel_shapes and metric1-16"],
+                        "test_lane_kernel_shapes and (metric1-16 or metric2-32)"],
                        env=env, capture_output=True, text=True, timeout=900,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     tail = r.stderr[:1500] + "\n...\n" + (r.stdout + r.stderr)[-2500:]
     assert r.returncode == 0, tail
     log = r.stdout + r.stderr
-    assert "cm mode=1 bwd=1" in log and "cm mode=2 bwd=1" in log, "the channel-MFMA backward was not dispatched\n" + tail
+    for ch in (16, 32):
+        assert f"cm mode=1 bwd=1 channels={ch}" in log and f"cm mode=2 bwd=1 channels={ch}" in log, \
+            f"the channel-MFMA backward was not dispatched for {ch} channels\n" + tail
     assert " passed" in log and "failed" not in log, tail
 
 
@@ -428,22 +430,27 @@ torch.save([g.cpu() for g in gs], sys.argv[2])
 """
 
 
-def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path):
-    """The opt-in channel-MFMA backward where every wave walks several row tiles (40 000 edges = 2 500 tiles on 1 024
-    waves; 3 000 nodes): d/dh and every parameter gradient against the default path (row-per-lane backward) of the same
-    layer, each in its own process (the switch is read once per process)."""
+@pytest.mark.parametrize("C", [16, 32])
+def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path, C):
+    """The channel-MFMA backward where every wave walks several row tiles with dynamic tile claims (40 000 edges = 2 500
+    tiles; 3 000 nodes): d/dh and every parameter gradient against the general row-tile kernels of the same layer
+    (CSMPN_NO_CM=1), each in its own process (the switches are read once per process)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for tag, extra in (("rl", {}), ("cm", {"CSMPN_CM_BWD": "1", "CSMPN_DEBUG": "1"})):
+    script = _CM_BWD_SCRIPT.replace("C, N, E = (1.0, 1.0, 1.0), 16,", f"C, N, E = (1.0, 1.0, 1.0), {C},")
+    assert f"{C}, 3000, 40000" in script
+    for tag, extra in (("general", {"CSMPN_NO_CM": "1", "CSMPN_DEBUG": "1"}), ("cm", {"CSMPN_DEBUG": "1"})):
         f = str(tmp_path / f"g_{tag}.pt")
-        r = subprocess.run([sys.executable, "-c", _CM_BWD_SCRIPT, root, f], env=dict(os.environ, **extra), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", script, root, f], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-3000:]
         if tag == "cm":
             assert "cm mode=1 bwd=1" in r.stderr and "cm mode=2 bwd=1" in r.stderr, r.stderr[-2000:]
+        else:
+            assert "cm mode=" not in r.stderr, r.stderr[-2000:]
         outs[tag] = torch.load(f)
-    for i, (a, b) in enumerate(zip(outs["cm"], outs["rl"])):
+    for i, (a, b) in enumerate(zip(outs["cm"], outs["general"])):
         err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
         assert err < 2e-5, (i, err)
 
@@ -479,7 +486,10 @@ def test_general_kernels_phased_backward(pkg, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs, logs = {}, {}
-    for tag, extra in (("phased", {"CSMPN_DEBUG": "1"}), ("whole", {"CSMPN_NO_PHASED": "1", "CSMPN_DEBUG": "1"})):
+    # round 4: the 32-channel layer itself runs on the channel-MFMA kernels now; CSMPN_NO_CM=1 leaves it to the general
+    # kernels, whose phased form still serves every other multi-block shape of the small algebras (24 / 40 / 48 channels, NBA)
+    for tag, extra in (("phased", {"CSMPN_DEBUG": "1", "CSMPN_NO_CM": "1"}),
+                       ("whole", {"CSMPN_NO_PHASED": "1", "CSMPN_DEBUG": "1", "CSMPN_NO_CM": "1"})):
         f = str(tmp_path / f"g_{tag}.pt")
         r = subprocess.run([sys.executable, "-c", _PHASED_SCRIPT, root, f], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600, cwd=root)

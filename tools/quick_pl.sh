@@ -10,5 +10,5 @@ if [ -z "$ONLY_M" ]; then hipcc $FLAGS $EXTRA -c k_pl_n5.hip -o $B/k_pl_n5.o & f
 if [ "$1" = "capi" ]; then hipcc $FLAGS -c capi.hip -o $B/capi.o & fi
 wait
 grep -E "Name:|VGPRs:|ScratchSize" /tmp/k_pl_n5m.log | sed 's/.*remark: [^ ]* //; s/\[-Rpass.*//' | paste - - - | sed 's/_ZN5csmpn15cemlp_pl_kernelINS_3AlgILi5ELj16EEE//'
-hipcc -shared -fPIC --offload-arch=gfx950 $B/capi.o $B/csr.o $B/glue.o $B/layers.o $B/k_n2.o $B/k_n3.o $B/k_n4.o $B/k_n4m.o $B/k_n5.o $B/k_n5m.o $B/k_rl_n3.o $B/k_pl_n5.o $B/k_pl_n5m.o $B/k_plw_n5.o $B/k_plw_n5m.o -o ../csmpn_hip/libcsmpn_hip.so
+hipcc -shared -fPIC --offload-arch=gfx950 $B/capi.o $B/csr.o $B/glue.o $B/layers.o $B/k_n2.o $B/k_n3.o $B/k_n4.o $B/k_n4m.o $B/k_n5.o $B/k_n5m.o $B/k_pl_n5.o $B/k_pl_n5m.o $B/k_plw_n5.o $B/k_plw_n5m.o -o ../csmpn_hip/libcsmpn_hip.so
 echo built
