@@ -187,8 +187,9 @@ class SimplicialBatch:
             perms = torch.tensor(list(itertools.permutations(range(d + 1))), device=rows.device)
             plan["rows"].append(rows)
             vt = vrows[rows][:, : d + 1]
-            # once per batch (the kernel clamps out-of-range rows instead of faulting: check here, where PyTorch
-            # indexing would have asserted)
+            # once per batch: the fused embedding kernels (csmpn_embed_cemlp_*) index the vertex features with these rows
+            # UNCHECKED (include/csmpn_hip.h states the precondition) and the composed path's gather clamps silently -
+            # check here, where PyTorch indexing would have asserted
             if vt.numel() and (int(vt.min()) < 0 or int(vt.max()) >= int(self.node_types.shape[0])):
                 raise IndexError(f"x_ind of the {d}-simplices points outside the batch ({int(vt.min())}..{int(vt.max())} "
                                  f"of {int(self.node_types.shape[0])} rows)")

@@ -133,6 +133,7 @@ def _load():
     sig("csmpn_readout_mse_forward", C.c_int, [C.c_int, vp, vp, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp])
     sig("csmpn_readout_mse_backward", C.c_int, [C.c_int, vp, i32, i64, i32, vp, i64, vp, vp, vp])
     sig("csmpn_last_error", C.c_char_p, [])
+    sig("csmpn_last_kernel", C.c_char_p, [])
     sig("csmpn_abi_version", C.c_int, [])
     sig("csmpn_build_target", C.c_char_p, [])
     return lib

@@ -22,12 +22,13 @@
 //    B = this lane's input blade contracts over the lane bits 4-5 = r_hi; D[(o,r0)][(c,r0')] is the wanted sum on
 //    r0 = r0' (half of the tile, the other half is discarded). One MFMA per (matrix, blade), no LDS transposition,
 //    accumulators (4 grades x f4 per matrix) persistent over the tile loop.
-//  * per-channel parameter gradients are lane-private running sums in registers (the lane's channel is fixed);
-//    the sum over the rows of a wave happens ONCE, at the end of the launch.
-//  * the backward runs ONE LAUNCH PER BLOCK (last block first; d/d(block input) rows travel through a [rows, C, D]
-//    region behind the saved block inputs): 48-80 accumulator registers + 35 running sums per launch instead of
-//    both blocks' at once. Every workgroup writes one slice of partial sums; cl_reduce_kernel adds the slices in a
-//    fixed order (no atomics on parameters: bit-reproducible).
+//  * per-channel parameter gradients are lane-private running sums in LDS (the lane's channel is fixed; ClSums);
+//    the sum over the rows of a wave happens ONCE per block, at its end.
+//  * the backward is ONE launch for all blocks, run block by block (last block first): 48-80 accumulator registers +
+//    35 running sums are alive per block instead of both blocks' at once; d/d(block input) rows travel through a
+//    [rows, C, D] region behind the saved block inputs (through L2: a wave reads in block k - 1 what it wrote itself
+//    in block k) or, with one tile per wave, stay in registers. Every workgroup writes one slice of partial sums per
+//    block; cl_reduce_kernel adds the slices of all blocks in a fixed order (no atomics on parameters: bit-reproducible).
 //  * gathers: a lane loads its own 32 bytes of a row (2 x 16 bytes); scatters go through a per-wave LDS tile so that
 //    one atomic instruction covers whole 256-byte rows, equal consecutive targets summed first.
 #pragma once
@@ -39,10 +40,12 @@ constexpr int kClWaves = 4;          // waves per workgroup
 constexpr int kClSliceCap = 512;     // workgroups of a backward launch = slices of partial sums per block
 constexpr int kClParStride = 36;     // floats per channel in the per-channel parameter table
 
-// Compiler barrier between the 16-byte vector stores into a staging tile and the float reads of the same LDS bytes (and
-// the next tile's stores behind them): the two access types carry different alias information - cemlp_cm.hpp met the
-// reordering this allows. Costs no instruction.
-#define CL_LDS_ORDER() asm volatile("" ::: "memory")
+// Ordering point between LDS accesses of DIFFERENT lanes of one wave (a lane stores into the per-wave staging tile, another
+// lane reads those bytes; and the next tile's stores behind those reads): the LDS executes a wave's operations in issue
+// order, so no wait is needed - but the compiler sees each lane's own stores and loads as disjoint addresses and may move
+// them across each other (cemlp_cm.hpp met exactly that). A compiler barrier + the wave-barrier intrinsic (a scheduling
+// barrier, no instruction) state the contract at every such hand-over.
+#define CL_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } while (0)
 CSMPN_DEV f4 cl_ld4(const float* p) { return *reinterpret_cast<const f4*>(p); }
 CSMPN_DEV void cl_st4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
 

@@ -283,6 +283,8 @@ int csmpn_simplex_rows(int n, const csmpn_vertex_block* blocks, int n_blocks, co
  *   out [n_simplices, O, D]: out[s] = sum over its n_orders rows of CEMLP(concat_v vertex_feat[verts[r][v]]).
  * Neither the [n_rows, I, D] input rows nor the [n_rows, O, D] per-order outputs exist in memory; the sum is taken in
  * registers in row order (no atomics). n_orders in {1, 2, 6}. save_inputs / saved_inputs as for csmpn_cemlp_* (rows = n_rows).
+ * PRECONDITION: every entry of verts lies in [0, n_feature_rows) - the kernels gather vertex_feat rows with them unchecked
+ * (an out-of-range entry is an out-of-bounds device read); callers validate once per batch (csmpn/data/complexes.py plan()).
  * backward: d/d(parameters) only (the features are data); g_out [n_simplices, O, D]. */
 int csmpn_embed_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
                               const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row,
