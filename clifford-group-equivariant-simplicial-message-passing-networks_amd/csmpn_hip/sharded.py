@@ -273,10 +273,13 @@ def node_bounds(n_nodes: int, world: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def balanced_node_cuts(in_degree: torch.Tensor, world: int):
+def balanced_node_cuts(in_degree: torch.Tensor, world: int, boundaries=None):
     """W + 1 cut points of the node range such that every slice receives about E / W adjacencies (prefix sum of the
     in-degree): the edge stage is the expensive one, so slices are balanced by incoming edges, not by node count. A hub
-    may leave a slice empty; cuts are non-decreasing and cover [0, N]."""
+    may leave a slice empty; cuts are non-decreasing and cover [0, N].
+    boundaries (sorted node positions, e.g. the `ptr` of a collated batch of complexes): every inner cut moves to the
+    nearest allowed position - no graph straddles two slices, so every adjacency has its source in the slice of its
+    target and partition B exchanges nothing between layers (DstPlan.local_share == 1)."""
     n = int(in_degree.shape[0])
     if world == 1:
         return [0, n]
@@ -287,9 +290,33 @@ def balanced_node_cuts(in_degree: torch.Tensor, world: int):
     targets = torch.tensor([total * r // world for r in range(1, world)], dtype=torch.int64)
     inner = torch.searchsorted(csum, targets, right=False).tolist()   # first node whose prefix reaches the target
     cuts = [0] + [min(max(int(c), 0), n) for c in inner] + [n]
+    if boundaries is not None:
+        b = torch.as_tensor(boundaries, dtype=torch.int64).cpu().flatten()
+        b = torch.unique(torch.cat([b, torch.tensor([0, n], dtype=torch.int64)]))
+        for i in range(1, len(cuts) - 1):
+            j = int(torch.searchsorted(b, torch.tensor(cuts[i])))
+            lo, hi = int(b[max(j - 1, 0)]), int(b[min(j, len(b) - 1)])
+            cuts[i] = lo if cuts[i] - lo <= hi - cuts[i] else hi
     for i in range(1, len(cuts)):
         cuts[i] = max(cuts[i], cuts[i - 1])
     return cuts
+
+
+def locality_order(edge_index: torch.Tensor, n_nodes: int) -> torch.Tensor:
+    """A node order for partition B on ONE large complex: reverse Cuthill-McKee over the (symmetrised) adjacency, so that
+    the two ends of an adjacency get nearby numbers and contiguous node slices keep most sources local (the overlapped
+    stack hides the exchange under exactly those edges). Returns perm with new_id = perm[old_id]; apply it to edge_index
+    (perm[edge_index]) and scatter the node rows (h_new[perm] = h). Host-side, once per complex (scipy). Collated batches
+    of small complexes need none of this: their nodes are grouped by graph already - cut at graph boundaries instead."""
+    import numpy as np
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    ei = edge_index.detach().cpu().numpy()
+    a = coo_matrix((np.ones(ei.shape[1], dtype=np.int8), (ei[0], ei[1])), shape=(n_nodes, n_nodes)).tocsr()
+    order = reverse_cuthill_mckee((a + a.T).tocsr(), symmetric_mode=True)   # order[new] = old
+    perm = np.empty(n_nodes, dtype=np.int64)
+    perm[order] = np.arange(n_nodes, dtype=np.int64)
+    return torch.from_numpy(perm)
 
 
 def _world(group):
@@ -387,22 +414,23 @@ class DstPlan:
     and the index tables that move rows between the natural layout [N] and the padded layout [W * per] the
     equal-size collectives need (per = longest slice; pad rows read a zero row / are dropped)."""
 
-    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None, balance=True, max_pad=1.5):
+    def __init__(self, edge_index, n_nodes, backend=ops.HipBackend, group=None, balance=True, max_pad=1.5, boundaries=None):
         self.world, self.rank = _world(group)
         self.multi = _multi(group)      # collectives are issued (world > 1, or the forced world-size-1 rehearsal)
         dev = edge_index.device
         dst = edge_index[1]
         if balance and self.world > 1:
             deg_all = torch.bincount(dst, minlength=n_nodes)
-            self.cuts = balanced_node_cuts(deg_all, self.world)
+            self.cuts = balanced_node_cuts(deg_all, self.world, boundaries)
             # The collectives move the padded layout W x per (per = longest slice in NODES): on complexes whose in-degree
             # is skewed (vertex / edge / triangle rows) cuts by in-degree alone let per grow towards N. Bound it: no slice
             # longer than max_pad x N / W nodes (round-3 ADVICE) - the edge balance gives way first.
             cap = max(1, int(-(-n_nodes * max_pad // self.world)))
-            for r in range(1, self.world):          # left to right: a slice that is too long hands nodes to the next one
-                self.cuts[r] = min(self.cuts[r], self.cuts[r - 1] + cap)
-            for r in range(self.world - 1, 0, -1):  # ... and right to left for the last slices
-                self.cuts[r] = max(self.cuts[r], self.cuts[r + 1] - cap)
+            if boundaries is None:   # (graph-aligned cuts stay where the graphs end)
+                for r in range(1, self.world):          # left to right: a slice that is too long hands nodes to the next one
+                    self.cuts[r] = min(self.cuts[r], self.cuts[r - 1] + cap)
+                for r in range(self.world - 1, 0, -1):  # ... and right to left for the last slices
+                    self.cuts[r] = max(self.cuts[r], self.cuts[r + 1] - cap)
         else:
             self.cuts = [node_bounds(n_nodes, self.world, r)[0] for r in range(self.world)] + [n_nodes]
         self.lo, self.hi = self.cuts[self.rank], self.cuts[self.rank + 1]
@@ -420,6 +448,8 @@ class DstPlan:
         loc = (src_own >= self.lo) & (src_own < self.hi)
         self.idx_loc = torch.nonzero(loc, as_tuple=False).squeeze(1)
         self.idx_rem = torch.nonzero(~loc, as_tuple=False).squeeze(1)
+        # share of the owned adjacencies whose source row is owned too (1.0: the layer needs no row of another rank)
+        self.local_share = float(self.idx_loc.numel()) / max(1, int(self.edge_ids.numel()))
         self._split = None
         self._backend = backend
         self._edge_index_owned = edge_index[:, self.edge_ids]
@@ -741,8 +771,9 @@ class DstPartitionedEGCL(torch.nn.Module):
         self.group = group
         self.balance = balance
 
-    def plan(self, edge_index, n_nodes) -> DstPlan:
-        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance)
+    def plan(self, edge_index, n_nodes, boundaries=None) -> DstPlan:
+        """boundaries: allowed cut positions (the `ptr` of a collated batch): graphs stay whole, see balanced_node_cuts."""
+        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance, boundaries=boundaries)
 
     def forward(self, h, plan: DstPlan, edge_attr_local=None, node_attr=None):
         layer = self.layer
@@ -765,8 +796,9 @@ class DstPartitionedStack(torch.nn.Module):
         self.balance = balance
         self.overlap = overlap     # collectives in flight under the local-source edges (_DstPartStackOverlapFn)
 
-    def plan(self, edge_index, n_nodes) -> DstPlan:
-        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance)
+    def plan(self, edge_index, n_nodes, boundaries=None) -> DstPlan:
+        """boundaries: allowed cut positions (the `ptr` of a collated batch): graphs stay whole, see balanced_node_cuts."""
+        return DstPlan(edge_index, n_nodes, self.backend, self.group, balance=self.balance, boundaries=boundaries)
 
     def forward(self, h, plan: DstPlan, edge_attr_local=None, node_attr=None):
         params, counts, specs = [], [], []
