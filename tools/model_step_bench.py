@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--model", default="hulls", choices=["hulls", "md17", "motion"])
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
+    ap.add_argument("--profile-ops", action="store_true", help="torch.profiler over 3 eager steps: the small GPU kernels by Python call site")
     args = ap.parse_args()
     importlib.import_module(PKG)
     from csmpn.data import complexes as cx
@@ -97,6 +98,15 @@ def main():
     for _ in range(5):
         eager()
     torch.cuda.synchronize()
+    if args.profile_ops:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for _ in range(3):
+                eager()
+            torch.cuda.synchronize()
+        print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=50,
+                                                            max_src_column_width=110))
+        return
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eager()
