@@ -15,6 +15,7 @@ MAX_BLOCKS = 4
 FLAG_WEIGHTS_PACKED = 1
 FLAG_NO_VALIDATE = 2
 FLAG_DETERMINISTIC = 4
+FLAG_SAVE_STATE = 8
 ERR_UNSUPPORTED, ERR_INVALID, ERR_HIP = 1, 2, 3
 
 # every symbol include/csmpn_hip.h declares

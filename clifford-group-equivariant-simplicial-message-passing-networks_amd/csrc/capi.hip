@@ -884,8 +884,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (debug_cl) fprintf(stderr, "[csmpn] cl mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
             HIP_TRY(launch_cemlp_cl_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
             if (handled) {
-                note_kernel("csmpn::cemlp_cl_%s_kernel<%s, %d, %d, %d, %d>", bwd ? "bwd" : "fwd", alg_name(id), channels, mode, plan.C.nblk,
-                            i0 - (mode == MODE_EDGE ? 1 : 2) * channels);
+                note_kernel("csmpn::cemlp_cl_%s_kernel<%s, %d, %d, %d, %d%s>", bwd ? "bwd" : "fwd", alg_name(id), channels, mode, plan.C.nblk,
+                            i0 - (mode == MODE_EDGE ? 1 : 2) * channels, !bwd ? "" : (io.save_state ? ", true" : ", false"));
                 return CSMPN_OK;
             }
         }
@@ -1193,7 +1193,13 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
     if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
-    if (cl_shape(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane backward likewise
+    if (cl_shape(n, blocks, n_blocks)) {
+        ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane / channel-MFMA backward likewise
+        // CSMPN_FLAG_SAVE_STATE (8-channel kernels): one [rows, O, D] region per block for its output in front of the layer norm
+        if (has_cemlp_cl_n3(MODE_EDGE, n_blocks, blocks[0].out_features, blocks[0].in_features) ||
+            has_cemlp_cl_n3(MODE_NODE, n_blocks, blocks[0].out_features, blocks[0].in_features))
+            ch += (size_t)n_blocks * blocks[0].out_features;
+    }
     else if (general_phased_shape(n, blocks, n_blocks)) ch *= 2;               // the general kernels' phased backward: one hand-over slot per saved input
     return ch << n;
 }
@@ -1265,6 +1271,7 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // standalone CEMLP: no row table, atomic-free parameter sums only
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
 }
 
@@ -1382,6 +1389,7 @@ int csmpn_egcl_edge_forward(const float* metric, int n, const csmpn_block_params
     io.seg[1].a = edge_attr; io.seg[1].ia = perm; io.seg[1].ch = attr_channels; io.seg[1].off = channels;
     io.agg = agg; io.dst = dst_sorted; io.src = src_sorted; io.perm = perm; io.save = save_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // agg is then the [E, O, D] message table
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     (void)N;
     return run_rows(id, plan, MODE_EDGE, false, io, (hipStream_t)stream, need_pack);
 }
@@ -1412,6 +1420,7 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     io.dst = dst_sorted; io.src = src_sorted; io.perm = perm;
     io.gy = g_agg; io.gx[0] = gh; io.gx[1] = g_edge_attr; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // gh is then the [E, C, D] per-edge gradient table
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     (void)N;
     return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream, need_pack);
 }
@@ -1451,6 +1460,7 @@ int csmpn_egcl_node_forward(const float* metric, int n, const csmpn_block_params
     const bool need_pack = !(flags & CSMPN_FLAG_WEIGHTS_PACKED);   // packed fragments are a matter of the general kernels: run_rows
     io.y = out; io.resid = residual ? h : nullptr; io.save = save_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // node stage: no row table, only atomic-free kernels qualify
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     return run_rows(id, plan, MODE_NODE, false, io, (hipStream_t)stream, need_pack);
 }
 
@@ -1475,6 +1485,7 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     io.gy = g_out; io.gx[0] = gh; io.gx[1] = g_agg; io.gx[2] = g_node_attr;
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream, need_pack);
 }
 

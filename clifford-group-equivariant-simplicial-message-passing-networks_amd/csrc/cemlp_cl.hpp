@@ -326,7 +326,7 @@ CSMPN_DEV void cl_weighted_gp(float (&out)[8], const float (&z)[8], const float 
 
 // the part of a block forward behind its MVLinear: S.y holds the MVLinear output (without bias)
 template <class ALG, int C, class TB, int BATCH>
-CSMPN_DEV void cl_block_tail(const float* ldsw, const float* ldsp, ClFwd& S, float (&out)[8], ClStamp& stamp, int sid) {
+CSMPN_DEV void cl_block_tail(const float* ldsw, const float* ldsp, ClFwd& S, float (&out)[8], ClStamp& stamp, int sid, bool have_s = false) {
     constexpr int D = ALG::D, G = ALG::G;
     static_assert(D == 8 && G == 4, "Cl(3,0)-shaped algebra");
     const f4 p0 = cl_ld4(ldsp + TB::par);   // b1, bL, la
@@ -356,6 +356,30 @@ CSMPN_DEV void cl_block_tail(const float* ldsw, const float* ldsp, ClFwd& S, flo
 #pragma unroll
     for (int d = 0; d < D; ++d) { S.R[d] = 0.f; L[d] = 0.f; }
     cl_mix<C, C, TB::WR, BATCH>(S.R, z, ldsw);
+    // CSMPN_FLAG_SAVE_STATE: with s given (have_s: the forward saved it) the backward's recompute stops behind linear_right
+    // and the normalisation denominators - no linear_left mix, no geometric product
+    if (have_s) {
+        const f4 sg = cl_ld4(ldsp + (TB::par + 12));
+        static_for<0, G>([&](auto g) {
+            constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
+            float qq = 0.f;
+            static_for<0, nd>([&](auto t) {
+                constexpr int d = d0 + decltype(t)::value;
+                qq += qsf<ALG, d> * S.R[d] * S.R[d];
+            });
+            const float m = __builtin_fmaf(sg[int(g)], cl_smooth_abs_sqrt(qq) - 1.0f, 1.0f);
+            S.invden[g] = fast_rcp(m + kEps);
+        });
+        float qs = 0.f;
+        static_for<0, D>([&](auto dd) {
+            constexpr int d = decltype(dd)::value;
+            qs += qsf<ALG, d> * S.s[d] * S.s[d];
+        });
+        S.qs = qs;
+        S.nl = cl_smooth_abs_sqrt(qs);
+        S.invMn = fast_rcp(__builtin_fmaf(cl_chan_sum<C>(S.nl), 1.0f / float(C), kEps));
+        return;
+    }
     cl_mix<C, C, TB::WL, BATCH>(L, z, ldsw);
     stamp(sid + 1);
     L[0] += p0.y;
@@ -839,6 +863,7 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 
     const long ntiles = (io.rows + RPW - 1) / RPW;
     const long tstride = (long)gridDim.x * kClWaves;
+    const bool save_s = NBLK > 1 && io.save_state != 0 && io.save != nullptr;
     // Software pipeline over the wave's tiles: the row pieces of tile t + 1 are requested (all together) BEFORE the stores
     // and atomics of tile t - vmcnt counts in issue order, a load behind an atomic waits for its acknowledgement
     // (~3000 cycles under load) - and the indices of tile t + 2 travel while tile t + 1 computes.
@@ -873,6 +898,10 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
             static_assert(C == 8, "experiment: 8 channels");
             if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 0, (size_t)T.row * ROW + c * D, S);
 #endif
+            if (save_s && T.valid) {   // CSMPN_FLAG_SAVE_STATE: s of block 0 -> region 2 behind [block-1 inputs | hand-over]
+                float* ps_ = io.save + ((size_t)2 * io.rows + (size_t)T.row) * ROW + c * D;
+                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 4, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+            }
         }
         if constexpr (NBLK > 1) {
 #pragma unroll
@@ -886,6 +915,10 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 #ifdef CL_X_SAVE
             if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 1, (size_t)T.row * ROW + c * D, S);
 #endif
+            if (save_s && T.valid) {   // ... s of block 1 -> region 3
+                float* ps_ = io.save + ((size_t)3 * io.rows + (size_t)T.row) * ROW + c * D;
+                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 4, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+            }
         }
         // next tile's rows, then this tile's stores
         const ClTile<C, MODE> Tc = T;
@@ -928,7 +961,7 @@ constexpr size_t cl_fwd_lds_bytes() {
 // gathers it by target) or from the hand-over rows io.plw_g1; d/d(input of block K) goes to the hand-over rows (K > 0)
 // or to the program's gradient targets (K = 0). Block K > 0 reads its input from the saved rows.
 struct ClCarry { f4 a, b; };
-template <class ALG, int C, int MODE, int NBLK, int NA, int K>
+template <class ALG, int C, int MODE, int NBLK, int NA, int K, bool SAVES>
 CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const ClCarry carry_in, bool single, ClStamp& stamp) {
     f4 carry_a = carry_in.a, carry_b = carry_in.b;
     using MP = ClMap<C>;
@@ -1013,10 +1046,17 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
             cl_xsave_load(io.plw_tabs, (size_t)io.rows, K, (size_t)Tc.lrow * ROW + c * D, S);
             cl_block_tail_saved<ALG, C, TB>(ldsp, S);
 #else
+            constexpr bool have_s = SAVES;   // compile time: a run-time switch between the two recomputes spills the node program
+            if constexpr (have_s) {   // CSMPN_FLAG_SAVE_STATE: the block's output in front of the layer norm, saved by the forward
+                const float* ps_ = io.saved + ((size_t)(2 + K) * (size_t)io.rows + (size_t)Tc.lrow) * ROW + c * D;
+                const f4 a_ = cl_ld4(ps_), b_ = cl_ld4(ps_ + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { S.s[i] = a_[i]; S.s[4 + i] = b_[i]; }
+            }
             static_for<0, NP>([&](auto p) { cl_mix<C, TB::period(p), TB::W1(p)>(S.y, x[p], ldsw); });
             stamp(2);
             float unused[D];
-            cl_block_tail<ALG, C, TB, 4>(ldsw, ldsp, S, unused, stamp, 3);
+            cl_block_tail<ALG, C, TB, 4>(ldsw, ldsp, S, unused, stamp, 3, have_s);
 #endif
             cl_block_backward<ALG, C, TB>(ldsw, ldsp, S, gout, gy, sm, accR, accL, stamp, 8);
         }
@@ -1193,7 +1233,7 @@ constexpr size_t cl_bwd_lds_bytes() {
 // (through L2: the region is not read earlier in the launch, its lines cannot sit stale in this CU's L1; the stores are
 // drained before the workgroup's barrier) - no grid-wide synchronisation, one prologue less, and the node program
 // (one tile per wave) is a single launch.
-template <class ALG, int C, int MODE, int NBLK, int NA>
+template <class ALG, int C, int MODE, int NBLK, int NA, bool SAVES = false>
 __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1218,11 +1258,11 @@ __global__ void __launch_bounds__(64 * kClWaves, 2) cemlp_cl_bwd_kernel(const De
     const bool single = ntiles <= (long)gridDim.x * kClWaves;   // one tile per wave: the hand-over stays in registers
     ClCarry carry{f4{0.f, 0.f, 0.f, 0.f}, f4{0.f, 0.f, 0.f, 0.f}};
     if constexpr (NBLK > 1) {
-        carry = cl_bwd_block<ALG, C, MODE, NBLK, NA, 1>(io, smem + TB0::total, smem + tabs, carry, single, stamp);
+        carry = cl_bwd_block<ALG, C, MODE, NBLK, NA, 1, SAVES>(io, smem + TB0::total, smem + tabs, carry, single, stamp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
         __syncthreads();                                   // ... and every wave is done with the images
     }
-    cl_bwd_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, smem + tabs, carry, single, stamp);
+    cl_bwd_block<ALG, C, MODE, NBLK, NA, 0, SAVES>(io, smem, smem + tabs, carry, single, stamp);
     stamp.flush(io.stamps, threadIdx.x & 63);
 }
 

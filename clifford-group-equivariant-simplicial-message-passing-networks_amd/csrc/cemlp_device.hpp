@@ -122,7 +122,7 @@ struct RowIO {
     // scattered; `agg` (forward) / `gx[0]` (backward) is an [rows, C, D] table in sorted edge order
     // that a segmented reduction sums afterwards in a fixed order
     int row_store;
-    int pad3_;
+    int save_state;         // CSMPN_FLAG_SAVE_STATE (cemlp_cl.hpp): the blocks' outputs in front of the layer norm are saved / available
     const float* plw_tabs;  // wide parity-lane kernels (cemlp_plw.hpp): rotation tables packed into the workspace
     float* plw_g1;          // ... backward: d/d(block-1 input) rows handed from the block-1 launch to the block-0 launch
     float* plw_part;        // ... backward: one slice of weight-gradient tiles per workgroup (added by plw_reduce_kernel)

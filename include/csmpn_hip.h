@@ -67,6 +67,14 @@ extern "C" {
                                        default). Every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
                                        csmpn_egcl_node_forward/backward and csmpn_cemlp_forward/backward, where it only
                                        selects the atomic-free parameter sums. */
+#define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, round 4: the forward ALSO stores every block's
+                                      * output in front of its layer norm ("s", [rows, O, D] per block) behind the saved block
+                                      * inputs and the hand-over region (csmpn_cemlp_saved_floats_per_row counts them), and
+                                      * the backward called with the same flag reads them instead of recomputing
+                                      * linear_left and the geometric product (measured on S1: edge forward +2.5 us, edge
+                                      * backward -6.5 us). Honoured by the Cl(3,0) 8-channel kernels, ignored elsewhere.
+                                      * Only for a saved buffer laid out for exactly the rows of the call (not a slice of
+                                      * a larger one): the regions are addressed by the call's row count. */
 
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */

@@ -17,7 +17,7 @@ gradient's dot product with a seeded Gaussian direction (both runs) plus, for pa
   model_motion.npz, model_nba.npz  (`make_model_golden.py motion nba`, round 3) the motion-capture and NBA task models
                     (motion_cssmpnn.py, nba_cssmpnn.py) in the same form as the two above.
   readout_hulls.npz (`make_model_golden.py readout`, round 3) the readout + loss stage of the hulls model on its own.
-  stages_hulls.npz  (`make_model_golden.py stages`, round 3) embedding output and x behind every EGCL layer of the
+  stages_hulls.npz / stages_md17.npz  (`make_model_golden.py stages [hulls md17]`, rounds 3 / 4) embedding output and x behind every EGCL layer of the
                     hulls model on model_hulls.npz's parameters and batch.
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
 loaded by file path so that the reference's `csmpn` namespace stays in front).
@@ -260,23 +260,25 @@ def make_nba():
     print("nba model: loss", out["f32/backprop_loss"], out["f64/backprop_loss"])
 
 
-def make_hulls_stages():
-    """Round 3: the intermediate tensors of the hulls model on model_hulls.npz's parameters and batch - the output of
-    embed_simplicial_complex (hulls_cssmpnn.py:96-125) and x behind each EGCL layer (hulls_cssmpnn.py:89-94) - so that
-    the embedding stage and the layer stack are pinned separately from the loss. Per tensor and per
-    run (float32, float64): its norm and its dot product with a seeded Gaussian direction; from the float64 run every
-    8th row whole (as float32)."""
-    ref = np.load(os.path.join(HERE, "model_hulls.npz"))
+def make_stages(kind="hulls"):
+    """The intermediate tensors of a task model on its loss fixture's parameters and batch (model_<kind>.npz) - the output
+    of embed_simplicial_complex (hulls_cssmpnn.py:96-125, md17_cssmpnn.py:85-120) and x behind each EGCL layer
+    (hulls_cssmpnn.py:89-94, md17_cssmpnn.py:160-164) - so that the embedding stage and the layer stack are
+    pinned separately from the loss. Round 3: hulls; round 4: md17. Per tensor and per run (float32, float64): its norm and
+    its dot product with a seeded Gaussian direction; from the float64 run every 8th row whole (as float32)."""
+    cls, seed, mk_batch, bseed = {"hulls": (HullsCliffordSharedSimplicialMPNN, 101, hulls_batch, 7),
+                                  "md17": (CliffordSharedSimplicialMPNN_md17, 202, md17_batch, 9)}[kind]
+    ref = np.load(os.path.join(HERE, f"model_{kind}.npz"))
     out = {}
-    torch.manual_seed(101)
-    model32 = HullsCliffordSharedSimplicialMPNN()
-    batch = hulls_batch(7)
+    torch.manual_seed(seed)
+    model32 = cls()
+    batch = mk_batch(bseed)
     sd = {k: v for k, v in model32.state_dict().items() if "algebra." not in k}
     for k, v in sd.items():   # the same model as the loss fixture
         assert np.array_equal(npy(v), ref["p/" + k]), k
     for dt_name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
         torch.set_default_dtype(dtype)
-        model = HullsCliffordSharedSimplicialMPNN()
+        model = cls()
         full = model.state_dict()
         for k, v in sd.items():
             full[k] = v.to(dtype)
@@ -284,8 +286,8 @@ def make_hulls_stages():
         got = {}
         emb = model.embed_simplicial_complex
 
-        def traced(graph, _f=emb):
-            x = _f(graph)
+        def traced(*a, _f=emb, **kw):
+            x = _f(*a, **kw)
             got["embedding"] = x.detach().clone()
             return x
         model.embed_simplicial_complex = traced
@@ -302,8 +304,8 @@ def make_hulls_stages():
             else:
                 out[f"f32/{k}/rows"] = npy(t[::8])
         torch.set_default_dtype(torch.float32)
-    np.savez_compressed(os.path.join(HERE, "stages_hulls.npz"), **out)
-    print("hulls stages:", {k: v.shape for k, v in out.items() if k.endswith("rows")})
+    np.savez_compressed(os.path.join(HERE, f"stages_{kind}.npz"), **out)
+    print(kind, "stages:", {k: v.shape for k, v in out.items() if k.endswith("rows")})
 
 
 def make_readout():
@@ -350,8 +352,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["readout"]:
         make_readout()
         sys.exit(0)
-    if sys.argv[1:] == ["stages"]:
-        make_hulls_stages()
+    if sys.argv[1:2] == ["stages"]:
+        for kind in (sys.argv[2:] or ["hulls"]):
+            make_stages(kind)
         sys.exit(0)
     which = sys.argv[1:] or ["md17", "hulls"]
     if "motion" in which:

@@ -455,6 +455,42 @@ def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path, C):
         assert err < 2e-5, (i, err)
 
 
+def test_save_state_matches_recompute(pkg, monkeypatch):
+    """CSMPN_FLAG_SAVE_STATE (round 4, Cl(3,0) 8-channel kernels): the forward also stores every block's output in front of
+    its layer norm and the backward reads it instead of recomputing linear_left + the geometric product - same gradients as
+    the recomputing backward (the saved values ARE the recomputed ones: differences are rounding of one fewer fused chain),
+    several tiles per wave, tile tail, duplicate targets; the dispatch log names the instantiation."""
+    from csmpn_hip import native, ops
+    metric, C, N, E = (1.0, 1.0, 1.0), 8, 700, 30001
+    layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev())
+    h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=9))
+    gout = torch.randn(N, C, 8, generator=torch.Generator().manual_seed(10)).to(dev())
+    outs, kernels = {}, {}
+    be, spec = ops.HipBackend, layer.spec()
+    csr = ops.get_csr(ei, N)
+    pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+    for tag, on in (("save", True), ("recompute", False)):
+        monkeypatch.setattr(ops, "_SAVE_STATE", on)
+        # the four stages on this thread (csmpn_last_kernel is per thread; autograd's backward runs on its own)
+        agg, st_e = be.edge_forward(spec, csr, h, ea, pe)
+        out, st_n = be.node_forward(spec, csr.deg, h, agg, na, pn)
+        gh, g_agg, _, views_n = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, st_n)
+        kn = native.lib().csmpn_last_kernel().decode()
+        _, views_e = be.edge_backward(spec, csr, h, ea, pe, g_agg, gh, False, st_e)
+        ke = native.lib().csmpn_last_kernel().decode()
+        torch.cuda.synchronize()
+        kernels[tag] = (kn, ke)
+        outs[tag] = [out, gh] + [v for v in list(views_e) + list(views_n) if v is not None]
+    for k in kernels["save"]:
+        assert "cemlp_cl_bwd_kernel" in k and k.endswith(", true>"), kernels
+    for k in kernels["recompute"]:
+        assert "cemlp_cl_bwd_kernel" in k and k.endswith(", false>"), kernels
+    assert len(outs["save"]) == len(outs["recompute"]) > 10
+    for i, (a, b) in enumerate(zip(outs["save"], outs["recompute"])):
+        err = relmax(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+        assert err < 2e-6, (i, err)
+
+
 _PHASED_SCRIPT = r"""
 import importlib, os, sys, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
