@@ -62,6 +62,21 @@ CSMPN_DEV void cp_wgrad(f4 (&acc)[4], const float* slotA, const float* slotB, in
     });
 }
 
+// two weight-gradient tiles that share the gradient operand: (a^T b0, a^T b1) - the A operand is read once and the two
+// accumulation chains are independent (a dependent MFMA waits for its predecessor's result)
+template <class ALG>
+CSMPN_DEV void cp_wgrad2(f4 (&acc0)[4], f4 (&acc1)[4], const float* slotA, const float* slotB0, const float* slotB1, int lane) {
+    static_for<0, 8>([&](auto d) {
+        constexpr int g = ALG::grade(d);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float a = slotA[d * 256 + 64 * s + lane];
+            acc0[g] = mfma16(a, slotB0[d * 256 + 64 * s + lane], acc0[g]);
+            acc1[g] = mfma16(a, slotB1[d * 256 + 64 * s + lane], acc1[g]);
+        }
+    });
+}
+
 // cm_scatter for half rows: the staged tile holds HALF floats per row, the table rows are STRIDE floats long (the
 // caller passes the table offset by its half)
 template <int HALF, int STRIDE, bool SUB>
@@ -178,7 +193,19 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
     const float* ldst = tab + cb_tofs(lane);
     const float* ldsp = tab + TF::par + kClParStride * (16 * p + q);
     auto PP = [&](int v) { return ldsp + 4 * v * kClParStride; };
+#ifdef CSMPN_STAMPS   // diagnostic build: the time spent at the pair's rendezvous goes to slot 11, not to the phase
+    auto pair_sync = [&]() {
+        CM_FENCE();
+        const unsigned long long ta = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        stamp.acc[11] += tb - ta;
+        stamp.t0 += tb - ta;
+        CM_FENCE();
+    };
+#else
     auto pair_sync = [&]() { CM_FENCE(); __syncthreads(); CM_FENCE(); };
+#endif
 
     // persistent sums: weight-gradient tiles of this wave's OUTPUT group against every input chunk / group
     f4 aW1[NCH][4], aWR[2][4], aWL[2][4];
@@ -347,8 +374,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         stamp(3);
         CM_FENCE();
         // ---- d/d(linear_left weight)[group p][group m] = ggp_p^T z_m; d/dz = WL^T ggp (both groups' ggp)
-        CPW cp_wgrad<ALG>(aWL[0], GG[p], XZ[0], lane);
-        CPW cp_wgrad<ALG>(aWL[1], GG[p], XZ[1], lane);
+        CPW cp_wgrad2<ALG>(aWL[0], aWL[1], GG[p], XZ[0], XZ[1], lane);
         f4 gz[8];
 #pragma unroll
         for (int d = 0; d < D; ++d) gz[d] = f4{0.f, 0.f, 0.f, 0.f};
@@ -399,8 +425,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         in.issue(io, T, p, q);
         asm volatile("" ::: "memory");
         pair_sync();
-        CPW cp_wgrad<ALG>(aWR[0], GG[p], XZ[0], lane);
-        CPW cp_wgrad<ALG>(aWR[1], GG[p], XZ[1], lane);
+        CPW cp_wgrad2<ALG>(aWR[0], aWR[1], GG[p], XZ[0], XZ[1], lane);
         mix_t(0, R);
         stamp(6);
         CM_FENCE();
@@ -438,14 +463,12 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         cp_put(GG[p], lane, gz);
         pair_sync();
         if constexpr (NFULL > 1) {   // node program: XZ holds the aggregate's halves; the first segment follows
-            CPW cp_wgrad<ALG>(aW1[2], GG[p], XZ[0], lane);
-            CPW cp_wgrad<ALG>(aW1[3], GG[p], XZ[1], lane);
+            CPW cp_wgrad2<ALG>(aW1[2], aW1[3], GG[p], XZ[0], XZ[1], lane);
             pair_sync();
             cp_put(XZ[p], lane, x0);
             pair_sync();
         }
-        CPW cp_wgrad<ALG>(aW1[0], GG[p], XZ[0], lane);
-        CPW cp_wgrad<ALG>(aW1[1], GG[p], XZ[1], lane);
+        CPW cp_wgrad2<ALG>(aW1[0], aW1[1], GG[p], XZ[0], XZ[1], lane);
         if constexpr (kAttr) CPW cp_wgrad<ALG>(aW1[NCH - 1], GG[p], XA, lane);
         // d/d(input): wave p emits the chunk p of every full-width segment: gx = sum over the gradient's groups W1^T gy
         f4 gyo[8];

@@ -26,6 +26,9 @@ namespace csmpn {
 
 constexpr int kPlWaves = 4;
 constexpr int kPlRows = 4;
+#ifndef CSMPN_PL_BWD_WAVES
+#define CSMPN_PL_BWD_WAVES 1
+#endif
 #ifndef CSMPN_PL_FWD_WAVES
 #define CSMPN_PL_FWD_WAVES 2
 #endif
@@ -853,7 +856,7 @@ CSMPN_DEV void pl_scatter(const float* sc, int rs, int t_add, int t_sub, float* 
 // the kernel. NBLK = 2 blocks of 8 channels; block 0 has I0 input channels.
 // MODE_EDGE: I0 = 8 + A; MODE_NODE: I0 = 16 + T.
 template <class ALG, int MODE, int NBLK, int I0, bool BWD>
-__global__ void __launch_bounds__(64 * kPlWaves, BWD ? 1 : CSMPN_PL_FWD_WAVES) cemlp_pl_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMPN_PL_FWD_WAVES) cemlp_pl_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);

@@ -26,7 +26,7 @@ CMB_BWD = ["setup(stage tables)", "input loads + W1 mix", "r:silu, z->P, gout->W
 # pair backward of the 32-channel layers (cemlp_cmp.hpp, round 4)
 CMP_BWD = ["setup(stage tables)", "input -> slots, W1 mix", "r:silu, z->slots, linR/L, gout load, norm+gp, row sums", "b:layernorm, ggp->slots",
            "b:wgrad WL, WL^T", "b:gp+norm per channel", "b:gR->slots, input again, wgrad WR, WR^T", "input -> slots, W1 mix (y again)",
-           "b:silu, gy->slots, wgrad W1, W1^T", "", "next tile + store/scatter", "", "", "", "", "", "", "end-of-block sums"]
+           "b:silu, gy->slots, wgrad W1, W1^T", "", "next tile + store/scatter", "waiting at the pair's rendezvous (all phases)", "", "", "", "", "", "end-of-block sums"]
 
 
 def main(workload="S1", family="cl"):
