@@ -26,6 +26,7 @@ EXPORTS = (
     "csmpn_geometric_product_backward",
     "csmpn_cemlp_workspace_bytes",
     "csmpn_cemlp_saved_floats_per_row",
+    "csmpn_cemlp_saved_floats",
     "csmpn_cemlp_forward",
     "csmpn_cemlp_backward",
     "csmpn_mvlinear_forward",
@@ -104,6 +105,7 @@ def _load():
     sig("csmpn_geometric_product_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, i64, vp])
     sig("csmpn_cemlp_workspace_bytes", sz, [C.c_int, bp, C.c_int])
     sig("csmpn_cemlp_saved_floats_per_row", sz, [C.c_int, bp, C.c_int])
+    sig("csmpn_cemlp_saved_floats", sz, [C.c_int, bp, C.c_int, i64])
     sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_mvlinear_forward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp])

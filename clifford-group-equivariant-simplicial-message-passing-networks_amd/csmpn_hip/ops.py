@@ -136,7 +136,9 @@ class CemlpBinding:
             self._saved_per_row = int(native.lib().csmpn_cemlp_saved_floats_per_row(self.n, self.params, self.nblk))
         if self._saved_per_row == 0 or rows == 0:
             return None
-        return torch.empty(rows * self._saved_per_row, dtype=torch.float32, device=device)
+        # the size of THIS launch: regions a launch of `rows` rows never touches are left out (csmpn_cemlp_saved_floats)
+        return torch.empty(int(native.lib().csmpn_cemlp_saved_floats(self.n, self.params, self.nblk, rows)),
+                           dtype=torch.float32, device=device)
 
     def workspace(self, device) -> torch.Tensor:
         return torch.empty(max(self._ws_bytes, 16), dtype=torch.uint8, device=device)

@@ -1186,6 +1186,17 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
     return CSMPN_OK;
 }
 
+size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows) {
+    if (rows <= 0) return 0;
+    size_t per = csmpn_cemlp_saved_floats_per_row(n, blocks, n_blocks);
+    // the general kernels' hand-over slots (one per saved input: the per-row figure doubles for them) are used by the phased
+    // backward only, and make_plan takes that form only from sw().phased_min_rows rows on (the same switch, read once)
+    if (per && !cl_shape(n, blocks, n_blocks) && !(n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) &&
+        general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows)
+        per /= 2;
+    return per * (size_t)rows;
+}
+
 size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks) {
     if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
     size_t ch = 0;

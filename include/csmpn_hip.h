@@ -143,6 +143,12 @@ size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int 
  * saved inputs that the backward uses as scratch (a block's phase / launch hands d/d(its input) to the previous block's
  * there): the buffer is written by the backward although the pointer is const. */
 size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks);
+/* Floats of the saved buffer of ONE launch over `rows` rows (round 4): rows * csmpn_cemlp_saved_floats_per_row() minus the
+ * regions a launch of that size never touches - the general kernels' hand-over region exists only for launches that can
+ * take the block-by-block backward (rows >= its threshold, default 4096; CSMPN_PHASED_MIN_ROWS): a 940-row node stage of a
+ * multi-block CEMLP of the small algebras pays half. A buffer of this size is valid for forward and backward of that
+ * launch; a larger one (the per-row figure) always is. */
+size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows);
 
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
 int csmpn_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
