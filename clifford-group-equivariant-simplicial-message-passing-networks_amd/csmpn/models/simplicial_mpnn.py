@@ -86,35 +86,50 @@ class SimplexEmbedding(nn.Module):
                 emb_feat = self.algebra.embed_grade(t0, g0).contiguous()      # [S, K, D]: no vertex-order blow-up
                 if "verts_i32" not in plan:
                     plan["verts_i32"] = [v.to(torch.int32).contiguous() for v in plan["verts"]]
+        # (Tried in round 4 and dropped: the modules of the dimensions as parallel branches on side streams - forward and,
+        # through autograd's stream rule, backward. Two long independent chains overlap in a replayed HIP graph (1 618 ->
+        # 851 us in a probe), these short forks do not pay for their joins: md17 step 3.13 -> 3.27 ms, hulls 4.80 -> 4.91.)
         for d in range(self.max_dim + 1):
             rows, pv, nperm = plan["rows"][d], plan["verts"][d], plan["nperm"][d]
             if rows.shape[0] == 0:
                 continue
-            if emb_feat is not None and d >= 1:
-                mod = self.cl_feature_embedding[d]
-                e = ops.embed_cemlp_apply(emb_feat, plan["verts_i32"][d], nperm, mod.binding(), mod.flat_params())
-                out = out.index_copy(0, rows, e)
-                continue
-            if fused:
-                from csmpn_hip import ops
-                x = ops.simplex_rows(n, [(t, g) for t, g in vertex_blocks], pv)   # one gather + embed kernel
-            else:
-                feats = []
-                for t, grade in vertex_blocks:
-                    g = t[pv]                                   # [rows, d+1, K, n_g]
-                    g = g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2])
-                    feats.append(self.algebra.embed_grade(g, grade))
-                x = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)).contiguous()
-            e = self.cl_feature_embedding[d](x)
-            out = out.index_copy(0, rows, e.reshape(rows.shape[0], nperm, self.hidden_features, D).sum(dim=1))
+            out = out.index_copy(0, rows, self._embed_dim(d, rows, pv, nperm, vertex_blocks, emb_feat, plan, fused, D))
         return out
+
+    def _embed_dim(self, d, rows, pv, nperm, vertex_blocks, emb_feat, plan, fused, D):
+        """Embedded d-simplices [len(rows), hidden, D] (summed over the vertex orders)."""
+        n = self.algebra.dim
+        if emb_feat is not None and d >= 1:
+            from csmpn_hip import ops
+            mod = self.cl_feature_embedding[d]
+            return ops.embed_cemlp_apply(emb_feat, plan["verts_i32"][d], nperm, mod.binding(), mod.flat_params())
+        if fused:
+            from csmpn_hip import ops
+            x = ops.simplex_rows(n, [(t, g) for t, g in vertex_blocks], pv)   # one gather + embed kernel
+        else:
+            feats = []
+            for t, grade in vertex_blocks:
+                g = t[pv]                                   # [rows, d+1, K, n_g]
+                g = g.reshape(g.shape[0], (d + 1) * t.shape[1], t.shape[2])
+                feats.append(self.algebra.embed_grade(g, grade))
+            x = (feats[0] if len(feats) == 1 else torch.cat(feats, dim=1)).contiguous()
+        e = self.cl_feature_embedding[d](x)
+        return e.reshape(rows.shape[0], nperm, self.hidden_features, D).sum(dim=1) if nperm > 1 else e
 
 
 def type_attributes(algebra: CliffordAlgebra, type_features: torch.Tensor, edge_index: torch.Tensor):
     """node_attr = per-simplex type features as scalar-blade multivectors, edge_attr = (source, target)."""
     node_attr = algebra.embed_grade(type_features.unsqueeze(-1), 0)
-    edge_attr = torch.cat((node_attr[edge_index[0]], node_attr[edge_index[1]]), dim=1)
+    # index_select, not node_attr[index]: the backward of advanced indexing sorts the index (11 launches, 155 us per md17
+    # step); index_select's is one index_add_
+    edge_attr = torch.cat((node_attr.index_select(0, edge_index[0]), node_attr.index_select(0, edge_index[1])), dim=1)
     return node_attr, edge_attr
+
+
+def type_embedding(table: nn.Embedding, types: torch.Tensor) -> torch.Tensor:
+    """sim_type_embedding(node_types) (md17_cssmpnn.py:122-133) as a row gather of the table: the same values; the backward
+    is one index_add_ instead of embedding_dense_backward (82 us for a 3 x 3 table on the md17 batch)."""
+    return table.weight.index_select(0, types)
 
 
 class HullsSimplicialMPNN(nn.Module):
@@ -195,7 +210,7 @@ class MD17SimplicialMPNN(nn.Module):
         per_graph = segment_mean(loc_node.reshape(-1, F_ * 3), plan["graph_of_vertex"], B).reshape(B, F_, 3)
         per_graph = per_graph.mean(dim=1, keepdim=True).expand(B, F_, 3)
         pos = batch.loc - per_graph[batch.x_ind_batch]
-        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
         x = self._embed(batch, [(pos, 1), (batch.vel, 1), (batch.charges, 0)])
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:
@@ -241,7 +256,7 @@ class MotionSimplicialMPNN(nn.Module):
         # positions relative to the mean vertex position of their graph (motion_cssmpnn.py:139-144)
         mean = segment_mean(node_pos, plan["graph_of_vertex"], B)
         pos = batch.pos.index_copy(0, vr, node_pos - mean[plan["graph_of_vertex"]])
-        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
         x = self._embed(batch, [(pos.unsqueeze(1), 1), (batch.vel.unsqueeze(1), 1)])
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
@@ -297,7 +312,7 @@ class NBASimplicialMPNN(nn.Module):
         F_ = batch.pos.shape[1]
         plan = batch.plan(self.max_dim)
         vr = plan["vertex_rows"]
-        node_attr, edge_attr = type_attributes(self.algebra, self.sim_type_embedding(batch.node_types), batch.edge_index)
+        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
         x = self.embed(batch, batch.pos, batch.vel)
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:

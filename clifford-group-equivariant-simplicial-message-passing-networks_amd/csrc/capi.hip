@@ -1060,37 +1060,44 @@ __global__ void mvlinear_bwd_x_kernel(const MvLinDesc P) {
 }
 
 // d/dW[o,i,g] += sum_{rows, d in g} gy[b,o,d] x[b,i,d];  d/dbias[o] += sum_rows gy[b,o,0].
-// A workgroup takes a slab of rows; thread t owns weight elements t, t + 256, ... and walks the slab
-// (x / gy rows of the slab are L1/L2 hits after the first touch); one atomic per element and slab.
-constexpr int kMvLinSlab = 64;
-// rows per workgroup: 64 for large inputs, fewer for small ones (a thread walks its slab serially: with 64 rows the
-// 128-vertex embedding of a convex-hulls batch took 260 us in two workgroups)
-inline int mvlinear_slab(long rows) {
-    long s = rows / 512;
-    return (int)(s < 4 ? 4 : (s > kMvLinSlab ? kMvLinSlab : s));
+// Thread = one weight (or bias) element, blockIdx.y = a slab of rows it walks (x / gy rows of a slab are L1 / L2 hits:
+// a wave's 64 elements share o or neighbour it); one atomic per element and slab. The slab is sized so that the launch
+// has ~512 workgroups (8..64 rows): the first version gave every workgroup ALL elements of a 4-row slab - 235 workgroups x 1 152
+// atomics onto the same 1 152 addresses took 28 us on the 940 rows of an md17 batch.
+inline int mvlinear_slab(long rows, int elem_blocks) {
+    long slabs = 512 / elem_blocks;
+    if (slabs < 1) slabs = 1;
+    long s = (rows + slabs - 1) / slabs;
+    return (int)(s < 8 ? 8 : (s > 64 ? 64 : s));
 }
 __global__ void mvlinear_bwd_w_kernel(const MvLinDesc P, int slab) {
-    const long r0 = (long)blockIdx.x * slab;
+    const long r0 = (long)blockIdx.y * slab;
     const long r1 = r0 + slab < P.rows ? r0 + slab : P.rows;
     const int ws = P.sub ? P.G : 1;
     const int nw = P.O * P.I * ws;
-    for (int e = threadIdx.x; e < nw + P.O; e += blockDim.x) {
-        float acc = 0.f;
-        if (e < nw) {
-            if (!P.gw) continue;
-            const int g = e % ws, i = (e / ws) % P.I, o = e / (ws * P.I);
-            for (long r = r0; r < r1; ++r) {
-                const float* gr = P.gy + (r * P.O + o) * P.D;
-                const float* xr = P.x + (r * P.I + i) * P.D;
-                for (int d = 0; d < P.D; ++d)
-                    if (!P.sub || P.grade[d] == g) acc = fmaf(gr[d], xr[d], acc);
-            }
-            if (P.gw) atomicAdd(P.gw + e, acc);
-        } else if (P.gb) {
-            const int o = e - nw;
-            for (long r = r0; r < r1; ++r) acc += P.gy[(r * P.O + o) * P.D];
-            atomicAdd(P.gb + o, acc);
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nw + P.O) return;
+    float acc = 0.f;
+    if (e < nw) {
+        if (!P.gw) return;
+        const int g = e % ws, i = (e / ws) % P.I, o = e / (ws * P.I);
+        // blades of grade g are contiguous (blade order: by grade): [d0, d1)
+        int d0 = 0, d1 = P.D;
+        if (P.sub) {
+            while (P.grade[d0] != g) ++d0;
+            d1 = d0;
+            while (d1 < P.D && P.grade[d1] == g) ++d1;
         }
+        for (long r = r0; r < r1; ++r) {
+            const float* gr = P.gy + (r * P.O + o) * P.D;
+            const float* xr = P.x + (r * P.I + i) * P.D;
+            for (int d = d0; d < d1; ++d) acc = fmaf(gr[d], xr[d], acc);
+        }
+        atomicAdd(P.gw + e, acc);
+    } else if (P.gb) {
+        const int o = e - nw;
+        for (long r = r0; r < r1; ++r) acc += P.gy[(r * P.O + o) * P.D];
+        atomicAdd(P.gb + o, acc);
     }
 }
 
@@ -1370,9 +1377,11 @@ int csmpn_mvlinear_backward(int n, const float* x, const float* weight, const fl
                            (hipStream_t)stream, P);
     }
     if (g_weight || g_bias) {   // the bias gradient comes from the same kernel: a frozen weight must not silence it
-        const int slab = mvlinear_slab(rows);
-        const unsigned grid = (unsigned)((rows + slab - 1) / slab);
-        hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, P, slab);
+        const int nelem = out_features * in_features * (P.sub ? P.G : 1) + out_features;
+        const unsigned eb = (unsigned)((nelem + block - 1) / block);
+        const int slab = mvlinear_slab(rows, (int)eb);
+        hipLaunchKernelGGL(mvlinear_bwd_w_kernel, dim3(eb, (unsigned)((rows + slab - 1) / slab)), dim3(block), 0,
+                           (hipStream_t)stream, P, slab);
     }
     HIP_TRY(hipGetLastError());
     return CSMPN_OK;

@@ -21,6 +21,62 @@ sys.path.insert(0, ROOT)
 PKG = "clifford-group-equivariant-simplicial-message-passing-networks_amd"
 
 
+def op_sites(eager, steps=2):
+    """GPU time of an eager step by (innermost frame of this repo, autograd node, kernel): where the small launches
+    come from. Chrome trace of torch.profiler: kernels -> launching runtime call by correlation id -> enclosing
+    python_function / cpu_op events of the same thread by time."""
+    import bisect
+    import collections
+    import tempfile
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for _ in range(steps):
+            eager()
+        torch.cuda.synchronize()
+    path = os.path.join(tempfile.mkdtemp(), "trace.json")
+    prof.export_chrome_trace(path)
+    ev = json.load(open(path))["traceEvents"]
+    launches, spans = {}, collections.defaultdict(list)
+    for e in ev:
+        if e.get("ph") != "X":
+            continue
+        cat = e.get("cat", "")
+        if cat in ("cuda_runtime", "cuda_driver") and "correlation" in e.get("args", {}):
+            launches[e["args"]["correlation"]] = e
+        elif cat in ("python_function", "cpu_op", "user_annotation"):
+            spans[(e["pid"], e["tid"])].append((e["ts"], e["ts"] + e["dur"], cat, e["name"]))
+    for v in spans.values():
+        v.sort()
+    starts = {k: [s[0] for s in v] for k, v in spans.items()}
+    table = collections.defaultdict(lambda: [0.0, 0])
+    for e in ev:
+        if e.get("ph") != "X" or e.get("cat") not in ("kernel", "gpu_memcpy", "gpu_memset"):
+            continue
+        la = launches.get(e.get("args", {}).get("correlation"))
+        site, node = "?", ""
+        if la is not None:
+            key = (la["pid"], la["tid"])
+            v, ts = spans.get(key, []), la["ts"]
+            i = bisect.bisect_right(starts.get(key, []), ts)
+            best_py, best_op = None, None
+            for s0, s1, cat, name in reversed(v[max(0, i - 4000):i]):
+                if s1 < ts:
+                    continue
+                if cat == "python_function" and best_py is None and ("csmpn" in name or "tools/" in name) and "<" not in name.split(":")[-1][:1]:
+                    best_py = name
+                if cat == "cpu_op" and (name.startswith("autograd::engine") or best_op is None):
+                    best_op = name
+            site = (best_py or "?").split("networks_amd/")[-1]
+            node = (best_op or "").replace("autograd::engine::evaluate_function: ", "bwd:")
+        k = (site[-70:], node[:40], e["name"][:60])
+        table[k][0] += e["dur"]
+        table[k][1] += 1
+    tot = sum(v[0] for v in table.values())
+    print(f"GPU time per step {tot / steps:.0f} us, {sum(v[1] for v in table.values()) / steps:.0f} launches")
+    for k, (us, n) in sorted(table.items(), key=lambda kv: -kv[1][0])[:90]:
+        print(f"{us / steps:8.1f} us {n / steps:5.1f}x  {k[0]:70s} {k[1]:40s} {k[2]}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
@@ -30,6 +86,7 @@ def main():
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     ap.add_argument("--profile-ops", action="store_true", help="torch.profiler over 3 eager steps: the small GPU kernels by Python call site")
+    ap.add_argument("--op-sites", action="store_true", help="GPU kernels of one eager step by the package line that launched them")
     args = ap.parse_args()
     importlib.import_module(PKG)
     from csmpn.data import complexes as cx
@@ -98,6 +155,9 @@ def main():
     for _ in range(5):
         eager()
     torch.cuda.synchronize()
+    if args.op_sites:
+        op_sites(eager)
+        return
     if args.profile_ops:
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
