@@ -186,9 +186,13 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = wave & 1, pair = wave >> 1;
     const int r = lane & 15, q = lane >> 4;
-    float* XZ[2] = {slots, slots + kCbSlot};           // halves of the block input / z
-    float* XA = slots + 2 * kCbSlot;                   // attribute chunk
-    float* GG[2] = {slots + 3 * kCbSlot, slots + 4 * kCbSlot};   // halves of the gradient tensor on its way through the mixes
+    // Slot pointers are plain offsets from `slots` (NOT an array of pointers indexed by p: the compiler loses the LDS
+    // address space through it and emits flat_load / flat_store - 320 + 96 per kernel, each waiting on vmcnt AND lgkmcnt).
+    float* const XZ0 = slots;                          // halves of the block input / z
+    float* const XZ1 = slots + kCbSlot;
+    float* const XZp = slots + p * kCbSlot;            // this wave's half
+    float* const XA = slots + 2 * kCbSlot;             // attribute chunk
+    float* const GGp = slots + (3 + p) * kCbSlot;      // halves of the gradient tensor on its way through the mixes: own
     const float* ldsa = tab + 4 * cb_unit(r, q);
     const float* ldst = tab + cb_tofs(lane);
     const float* ldsp = tab + TF::par + kClParStride * (16 * p + q);
@@ -234,7 +238,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
     in.issue(io, T, p, q);
     for (long it = 0; it < iters; ++it, tile += tstride) {
         asm volatile("" ::: "memory");
-        // ---- the block's input: own half -> XZ[p] (+ attributes -> XA), y = W1 x over all chunks
+        // ---- the block's input: own half -> XZp (+ attributes -> XA), y = W1 x over all chunks
         float* const XZo = slots + (1 - p) * kCbSlot;   // the partner's half
         float* const GGo = slots + (4 - p) * kCbSlot;
         // table entries: W1 (g, m', chunk) -> w1e(m', chunk); linear_right / left (which, g, m', m) -> wce(which, m', m)
@@ -252,7 +256,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         auto mvlinear = [&](f4 (&keep)[8], bool put_attr) __attribute__((always_inline)) {
             f4 x1[8], xa[8];
             in.finish(keep, x1, xa, T);
-            cp_put(XZ[p], lane, keep);
+            cp_put(XZp, lane, keep);
             if constexpr (kAttr) { if (put_attr && p == 0) cp_put(XA, lane, xa); }
             pair_sync();
 #pragma unroll
@@ -265,7 +269,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             }
             if constexpr (NFULL > 1) {   // node program: the aggregate's two chunks through the same slots
                 pair_sync();
-                cp_put(XZ[p], lane, x1);
+                cp_put(XZp, lane, x1);
                 pair_sync();
                 mix_w1(1, x1);
             }
@@ -274,7 +278,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             f4 x0[8];
             mvlinear(x0, true);
         }
-        stamp(1);
+        stamp(1); CB_MARK(1);
         CM_FENCE();
         // ---- forward again: z = gate(y) y; R = WR z, s = (WL z + bL + gp(z, n(R))) / sqrt 2
         f4 z[8], R[8], s[8];
@@ -290,7 +294,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             CM_FENCE();
         });
         pair_sync();                 // everybody is done with the input chunks
-        cp_put(XZ[p], lane, z);
+        cp_put(XZp, lane, z);
         pair_sync();
 #pragma unroll
         for (int d = 0; d < D; ++d) R[d] = s[d] = f4{0.f, 0.f, 0.f, 0.f};
@@ -327,7 +331,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         if (q == 0) red[(0 * 2 + p) * 16 + r] = nl_own;
         pair_sync();
         const float invMn = fast_rcp(__builtin_fmaf(nl_own + red[(0 * 2 + (1 - p)) * 16 + r], 1.0f / float(C), kEps));
-        stamp(2);
+        stamp(2); CB_MARK(2);
         CM_FENCE();
         // ---- MVLayerNorm backward -> ggp = d/d(gp + linear_left output)
         f4 ggp[8];
@@ -369,12 +373,12 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             });
             sm[0] += cb_rows_sum<8>(sums, r);
         }
-        cp_put(GG[p], lane, ggp);
+        cp_put(GGp, lane, ggp);
         pair_sync();
-        stamp(3);
+        stamp(3); CB_MARK(3);
         CM_FENCE();
         // ---- d/d(linear_left weight)[group p][group m] = ggp_p^T z_m; d/dz = WL^T ggp (both groups' ggp)
-        CPW cp_wgrad2<ALG>(aWL[0], aWL[1], GG[p], XZ[0], XZ[1], lane);
+        CPW cp_wgrad2<ALG>(aWL[0], aWL[1], GGp, XZ0, XZ1, lane);
         f4 gz[8];
 #pragma unroll
         for (int d = 0; d < D; ++d) gz[d] = f4{0.f, 0.f, 0.f, 0.f};
@@ -386,7 +390,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             cb_mix_t<ALG, GSC>(gz, oth, ldst + wce(which, 1 - p, p));
         };
         mix_t(1, ggp);
-        stamp(4);
+        stamp(4); CB_MARK(4);
         CM_FENCE();
 #ifndef CP_X_NOGP
         // ---- geometric product + normalisation backward, per channel: R becomes d/dR
@@ -396,8 +400,8 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                 float gg[D], zf[D], RR[D], gzz[D], gRR[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) {   // d/d(gp) and z of this channel come back from the slots: 64 registers less in this phase
-                    gg[d] = GG[p][d * 256 + r * 16 + 4 * q + int(v)];
-                    zf[d] = XZ[p][d * 256 + r * 16 + 4 * q + int(v)];
+                    gg[d] = GGp[d * 256 + r * 16 + 4 * q + int(v)];
+                    zf[d] = XZp[d * 256 + r * 16 + 4 * q + int(v)];
                     RR[d] = R[d][int(v)];
                 }
                 cp_pin8(RR);
@@ -416,23 +420,23 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             });
         }
 #endif
-        stamp(5);
+        stamp(5); CB_MARK(5);
         CM_FENCE();
         pair_sync();                 // everybody is done with ggp in GG
-        cp_put(GG[p], lane, R);
+        cp_put(GGp, lane, R);
         // the input again (the gates' argument y = W1 x; d/dW1's operand): requested here, it travels under the MFMAs below
         asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
         in.issue(io, T, p, q);
         asm volatile("" ::: "memory");
         pair_sync();
-        CPW cp_wgrad2<ALG>(aWR[0], aWR[1], GG[p], XZ[0], XZ[1], lane);
+        CPW cp_wgrad2<ALG>(aWR[0], aWR[1], GGp, XZ0, XZ1, lane);
         mix_t(0, R);
-        stamp(6);
+        stamp(6); CB_MARK(6);
         CM_FENCE();
         pair_sync();                 // z and d/dR are no longer read
         f4 x0[8];
         mvlinear(x0, false);
-        stamp(7);
+        stamp(7); CB_MARK(7);
         CM_FENCE();
 #ifndef CP_X_NOSILU
         // ---- MVSiLU backward: gz becomes d/dy
@@ -460,16 +464,16 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         }
 #endif
         // ---- d/dy through the slots: d/dW1 against the input chunks in XZ / XA, d/d(input)
-        cp_put(GG[p], lane, gz);
+        cp_put(GGp, lane, gz);
         pair_sync();
         if constexpr (NFULL > 1) {   // node program: XZ holds the aggregate's halves; the first segment follows
-            CPW cp_wgrad2<ALG>(aW1[2], aW1[3], GG[p], XZ[0], XZ[1], lane);
+            CPW cp_wgrad2<ALG>(aW1[2], aW1[3], GGp, XZ0, XZ1, lane);
             pair_sync();
-            cp_put(XZ[p], lane, x0);
+            cp_put(XZp, lane, x0);
             pair_sync();
         }
-        CPW cp_wgrad2<ALG>(aW1[0], aW1[1], GG[p], XZ[0], XZ[1], lane);
-        if constexpr (kAttr) CPW cp_wgrad<ALG>(aW1[NCH - 1], GG[p], XA, lane);
+        CPW cp_wgrad2<ALG>(aW1[0], aW1[1], GGp, XZ0, XZ1, lane);
+        if constexpr (kAttr) CPW cp_wgrad<ALG>(aW1[NCH - 1], GGp, XA, lane);
         // d/d(input): wave p emits the chunk p of every full-width segment: gx = sum over the gradient's groups W1^T gy
         f4 gyo[8];
         cp_get(GGo, lane, gyo);
@@ -481,7 +485,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         };
         f4 gx0[8];
         gx_of(p, gx0);
-        stamp(8);
+        stamp(8); CB_MARK(8);
         CM_FENCE();
         // the next tile's rows leave in front of this tile's stores / atomics
         const CmTile<MODE> Tc = T;
@@ -509,7 +513,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                 if (io.row_store) {
                     if (Tc.valid) cm_store_piece(io.gx[0] + (size_t)Tc.lrow * ROW + coff, gx0);
                 } else {
-                    pair_sync();     // the slots are free: this wave stages its half rows in XZ[p] (.. + SS rows fit one slot + 64 floats of XA's neighbour: use GG/XZ pair)
+                    pair_sync();     // the slots are free: this wave stages its half rows in XZp (.. + SS rows fit one slot + 64 floats of XA's neighbour: use GG/XZ pair)
                     float* sc = slots + 3 * p * kCbSlot;   // XZ[0..1] | GG[0..1]: 16 x (HALF + 4) floats = 2112 <= two adjacent slots
                     cm_store_piece(sc + r * SS + q * D, gx0);
                     cb_sync();
@@ -552,7 +556,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             }
         }
         pair_sync();                 // the slots are free for the next tile
-        stamp(10);
+        stamp(10); CB_MARK(10);
         CM_FENCE();
     }
 
@@ -603,7 +607,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                   (size_t)blockIdx.x * PT::total;
     static_assert(PT::total % 4 == 0, "slice length");
     for (int e = 4 * threadIdx.x; e < PT::total; e += 4 * 64 * kCpWaves) cl_st4(part + e, cl_ld4(img + e));
-    stamp(17);
+    stamp(17); CB_MARK(17);
     CM_FENCE();
 }
 
