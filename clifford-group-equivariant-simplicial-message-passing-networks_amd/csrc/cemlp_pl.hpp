@@ -753,13 +753,23 @@ CSMPN_DEV void pl_store_small(float* slice_tail, float* sc, const float* tot, co
     }
     tile_sync<VAR_WAVE>();
 }
-// grads += sum over the waves' slices, fixed order; one thread per slice element (64 per workgroup x 4 slice subsets)
+// slice subsets of the reduce kernels (cemlp_pl.hpp, cemlp_plw.hpp): 64 slice positions x kPlReduceSubs subsets per workgroup
+constexpr int kPlReduceSubs = 16;
+// fixed-order sum of the subsets' partial sums of position `pos`
+CSMPN_DEV float pl_reduce_combine(const float (&red)[kPlReduceSubs][64], int pos) {
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < kPlReduceSubs; k += 4) a += (red[k][pos] + red[k + 1][pos]) + (red[k + 2][pos] + red[k + 3][pos]);
+    return a;
+}
+// grads += sum over the waves' slices, fixed order; one thread per slice element (64 per workgroup x 16 slice subsets:
+// with 4 subsets the 1 024 slices of an S3 launch took 23.7 us)
 template <class ALG, int NBLK, int I0>
-__global__ void __launch_bounds__(256) pl_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
+__global__ void __launch_bounds__(64 * kPlReduceSubs) pl_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
     using LY = PlLay<ALG, NBLK, I0>;
     using PP = PlPart<LY>;
-    constexpr int GC = LY::GC, G = ALG::G, C = LY::C, NCH0 = PP::NCH0, NP = ALG::P;
-    __shared__ float red[4][64];
+    constexpr int GC = LY::GC, G = ALG::G, C = LY::C, NCH0 = PP::NCH0, NP = ALG::P, NS = kPlReduceSubs;
+    __shared__ float red[NS][64];
     const int sub = threadIdx.x >> 6;
     const long t = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     float* dst = nullptr;
@@ -793,17 +803,17 @@ __global__ void __launch_bounds__(256) pl_reduce_kernel(const DevCemlp Cd, const
     if (dst) {
         const float* p = part + t;
         int g = sub;
-        for (; g + 12 < nslices; g += 16) {
+        for (; g + 3 * NS < nslices; g += 4 * NS) {
             s0 += p[(size_t)g * PP::slice];
-            s1 += p[(size_t)(g + 4) * PP::slice];
-            s2 += p[(size_t)(g + 8) * PP::slice];
-            s3 += p[(size_t)(g + 12) * PP::slice];
+            s1 += p[(size_t)(g + NS) * PP::slice];
+            s2 += p[(size_t)(g + 2 * NS) * PP::slice];
+            s3 += p[(size_t)(g + 3 * NS) * PP::slice];
         }
-        for (; g < nslices; g += 4) s0 += p[(size_t)g * PP::slice];
+        for (; g < nslices; g += NS) s0 += p[(size_t)g * PP::slice];
     }
     red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sub == 0 && dst) *dst += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sub == 0 && dst) *dst += pl_reduce_combine(red, threadIdx.x);
 }
 
 // staged rows -> global. The staging tile holds kPlRows rows of `ncol` floats (row stride rs).

@@ -667,11 +667,12 @@ CSMPN_DEV void plw_store_tile(float* slice, int tile_idx, const f4 (&acc)[PS<ALG
 // grads += sum over the workgroups' slices; one thread per (slot, thread position): a single writer per gradient
 // element, fixed summation order
 template <class ALG, class CF, int BLK>
-__global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngroups) {
+__global__ void __launch_bounds__(64 * kPlReduceSubs) plw_reduce_kernel(const DevCemlp Cd, const float* part, int ngroups) {
     using PP = PlwPart<CF, BLK>;
-    constexpr int GC = CF::GC, NG = CF::NG, NT = PP::NT, G = ALG::G, C = CF::C;
-    // 64 slice positions per workgroup x 4 interleaved group subsets (independent loads in flight), combined in LDS
-    __shared__ float red[4][64];
+    constexpr int GC = CF::GC, NG = CF::NG, NT = PP::NT, G = ALG::G, C = CF::C, NS = kPlReduceSubs;
+    // 64 slice positions per workgroup x 16 interleaved group subsets (4 independent loads in flight each), combined in
+    // LDS in a fixed order. (4 subsets: 13 us per launch on the 256 slices of a convex-hulls batch, 14 launches per step.)
+    __shared__ float red[NS][64];
     const int sub = threadIdx.x >> 6;
     const long t = (long)blockIdx.x * 64 + (threadIdx.x & 63);
     const bool in = t < PP::w_floats + PP::i_tot;
@@ -712,20 +713,17 @@ __global__ void __launch_bounds__(256) plw_reduce_kernel(const DevCemlp Cd, cons
     if (live) {
         const float* p = part + t;
         int g = sub;
-        for (; g + 12 < ngroups; g += 16) {
+        for (; g + 3 * NS < ngroups; g += 4 * NS) {
             s0 += p[(size_t)g * PP::slice];
-            s1 += p[(size_t)(g + 4) * PP::slice];
-            s2 += p[(size_t)(g + 8) * PP::slice];
-            s3 += p[(size_t)(g + 12) * PP::slice];
+            s1 += p[(size_t)(g + NS) * PP::slice];
+            s2 += p[(size_t)(g + 2 * NS) * PP::slice];
+            s3 += p[(size_t)(g + 3 * NS) * PP::slice];
         }
-        for (; g < ngroups; g += 4) s0 += p[(size_t)g * PP::slice];
+        for (; g < ngroups; g += NS) s0 += p[(size_t)g * PP::slice];
     }
     red[sub][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sub == 0 && live) {
-        const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        *dst += sum;
-    }
+    if (sub == 0 && live) *dst += pl_reduce_combine(red, threadIdx.x);
 }
 
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
