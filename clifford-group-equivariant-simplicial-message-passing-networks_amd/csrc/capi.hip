@@ -855,7 +855,8 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (id == ALG_N5) HIP_TRY(launch_cemlp_pl_n5(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
             else HIP_TRY(launch_cemlp_pl_n5m(mode, plan.C.nblk, 8, i0, bwd, grid, st, plan.C, io, &handled));
             if (handled) {
-                note_kernel("csmpn::cemlp_pl_kernel<%s, %d, %d, %d, %s>", alg_name(id), mode, plan.C.nblk, i0, bwd ? "true" : "false");
+                note_kernel("csmpn::cemlp_pl_kernel<%s, %d, %d, %d, %s, %s>", alg_name(id), mode, plan.C.nblk, i0, bwd ? "true" : "false",
+                            bwd && io.save_state ? "true" : "false");
                 return CSMPN_OK;
             }
         }
@@ -1210,7 +1211,11 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     for (int k = 0; k + 1 < n_blocks; ++k) ch += (size_t)blocks[k].out_features;
     // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
-    if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
+    if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) {
+        ch += (size_t)blocks[0].out_features;
+        // CSMPN_FLAG_SAVE_STATE (8-channel parity-lane kernels, cemlp_pl.hpp): regions 2, 3 = the blocks' outputs in front of their layer norms
+        if (blocks[0].out_features == 8) ch += (size_t)n_blocks * 8;
+    }
     if (cl_shape(n, blocks, n_blocks)) {
         ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane / channel-MFMA backward likewise
         // CSMPN_FLAG_SAVE_STATE (8-channel kernels): one [rows, O, D] region per block for its output in front of the layer norm

@@ -496,13 +496,24 @@ struct PlSumIdx {
 constexpr int kPlThreads = 64 * kPlWaves;
 CSMPN_DEV void pl_sum_add(float* slot, float v) { *slot = *slot + v; }
 
-// block forward behind the MVLinear: S.y holds the MVLinear output (without bias)
-template <class ALG, class LY, int K>
-CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG>& S, float (&out)[PS<ALG>::DL]) {
+// block forward behind the MVLinear: S.y holds the MVLinear output (without bias).
+// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_row points at this lane's channel row of the block's output in front of
+// its layer norm, stored by the forward - the recompute stops behind linear_right and the normalisation: no linear_left
+// mix, no geometric product (the most expensive phase at D = 32). The row is requested first and picked up behind the
+// normalisation.
+template <class ALG, class LY, int K, bool SAVED = false>
+CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG>& S, float (&out)[PS<ALG>::DL],
+                             const float* s_row = nullptr) {
     using P = PS<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G;
     const float* ldsn = lds + ge.n;
     const int c = ge.c;
+    f4 sv[ALG::D / 4];
+    if constexpr (SAVED) {
+#pragma unroll
+        for (int e = 0; e < ALG::D / 4; ++e) sv[e] = pl_ld4(s_row + 4 * e);
+        asm volatile("" ::: "memory");
+    }
     if (ge.s == 0) S.y[0] += lds[LY::p_b1(K) + c];
     // MVSiLU (cegnn_utils.py:76-83)
     float z[DL];
@@ -525,11 +536,8 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     float L[DL];
 #pragma unroll
     for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
-#ifndef PL_X_NOLIN
-    pl_linear2<ALG, LY::t_WR(K), LY::t_WL(K)>(S.R, L, z, ldsn);
-#else
-    for (int j = 0; j < DL; ++j) { S.R[j] = z[j]; L[j] = z[(j + 1) % DL]; }
-#endif
+    if constexpr (SAVED) pl_linear<ALG, LY::t_WR(K)>(S.R, z, ldsn);
+    else pl_linear2<ALG, LY::t_WR(K), LY::t_WL(K)>(S.R, L, z, ldsn);
     if (ge.s == 0) L[0] += lds[LY::p_bL(K) + c];
     CSMPN_PHASE();
     // NormalizationLayer on the right operand (cegnn_utils.py:42-51)
@@ -548,11 +556,13 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     });
     CSMPN_PHASE();
     // steerable geometric product + first-order term (cegnn_utils.py:126-152)
-#ifndef PL_X_NOGP
-    pl_weighted_gp<ALG>(L, z, r, lds + LY::p_w(K) + c * ALG::P, ge);
-#endif
+    if constexpr (SAVED) {
+        pl_pick<ALG>(S.s, sv, ge.s, 1.0f);
+    } else {
+        pl_weighted_gp<ALG>(L, z, r, lds + LY::p_w(K) + c * ALG::P, ge);
 #pragma unroll
-    for (int j = 0; j < DL; ++j) S.s[j] = L[j] * kInvSqrt2;
+        for (int j = 0; j < DL; ++j) S.s[j] = L[j] * kInvSqrt2;
+    }
     CSMPN_PHASE();
     // MVLayerNorm (cegnn_utils.py:93-96): q over all blades = own half + partner's half
     float qs = 0.f;
@@ -865,7 +875,9 @@ CSMPN_DEV void pl_scatter(const float* sc, int rs, int t_add, int t_sub, float* 
 // ---------------------------------------------------------------------------------
 // the kernel. NBLK = 2 blocks of 8 channels; block 0 has I0 input channels.
 // MODE_EDGE: I0 = 8 + A; MODE_NODE: I0 = 16 + T.
-template <class ALG, int MODE, int NBLK, int I0, bool BWD>
+// SAVES (backward): the forward ran with CSMPN_FLAG_SAVE_STATE - regions 2 and 3 behind [block-1 inputs | hand-over] of the
+// saved buffer hold the outputs of block 0 / 1 in front of their layer norms (a compile-time choice, as in cemlp_cl.hpp).
+template <class ALG, int MODE, int NBLK, int I0, bool BWD, bool SAVES = false>
 __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMPN_PL_FWD_WAVES) cemlp_pl_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -983,8 +995,19 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
         if constexpr (!BWD) {
             PlState<ALG> S;
             float out[DL];
+            const bool save_s = io.save_state != 0 && io.save != nullptr;
+            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s rows -> region `region` of the saved buffer
+                tile_sync<VAR_WAVE>();
+                pl_stage<ALG>(sc, S.s, ge, RS, true);
+                tile_sync<VAR_WAVE>();
+                pl_copy_rows(sc, RS, ROW, ge.lane, [&](int r) -> float* {
+                    const long rr = tile * kPlRows + r;
+                    return rr < io.rows ? io.save + ((size_t)region * io.rows + rr) * ROW : nullptr;
+                });
+            };
             mvlinear0(S.y);
             pl_block_tail<ALG, LY, 0>(lds, ge, S, out);
+            if (save_s) store_s(2);
             if (io.save) {
                 tile_sync<VAR_WAVE>();
                 pl_stage<ALG>(sc, out, ge, RS, true);
@@ -1001,6 +1024,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
             }
             pl_block_tail<ALG, LY, 1>(lds, ge, S, out);
+            if (save_s) store_s(3);
             if constexpr (MODE == MODE_NODE) {
                 if (io.resid) {
                     float res[DL];
@@ -1044,7 +1068,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
 #pragma unroll
                     for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                     pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
-                    pl_block_tail<ALG, LY, 1>(lds, ge, S, unused);
+                    pl_block_tail<ALG, LY, 1, SAVES>(lds, ge, S, unused, io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs);
                     pl_block_backward<ALG, LY, 1>(lds, ge, S, gout, gy, tot1, aWR_1, aWL_1);
                 }
                 pl_wgrad<ALG>(aW1_1, gy, in1);
@@ -1058,7 +1082,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 PlState<ALG> S;
                 float unused[DL];
                 mvlinear0(S.y);
-                pl_block_tail<ALG, LY, 0>(lds, ge, S, unused);
+                pl_block_tail<ALG, LY, 0, SAVES>(lds, ge, S, unused, io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs);
                 pl_block_backward<ALG, LY, 0>(lds, ge, S, g1, gy0, tot0, aWR_0, aWL_0);
             }
             CSMPN_PHASE();
