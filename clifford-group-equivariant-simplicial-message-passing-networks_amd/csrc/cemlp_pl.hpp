@@ -496,9 +496,20 @@ struct PlSumIdx {
 constexpr int kPlThreads = 64 * kPlWaves;
 CSMPN_DEV void pl_sum_add(float* slot, float v) { *slot = *slot + v; }
 
+// CSMPN_FLAG_SAVE_STATE: a block's output in front of its layer norm is private to these kernels and kept in LANE order -
+// [row][channel][parity][16 slots], 64 contiguous bytes per lane: four 16-byte stores in the forward, four loads in the
+// backward, no staging tile and no pick of the parity's blades.
+template <class ALG>
+CSMPN_DEV void pl_store_s(float* p, const float (&sv)[PS<ALG>::DL]) {
+    static_assert(PS<ALG>::DL % 4 == 0, "whole 16-byte pieces");
+#pragma unroll
+    for (int e = 0; e < PS<ALG>::DL / 4; ++e)
+        *reinterpret_cast<f4*>(p + 4 * e) = f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]};
+}
+
 // block forward behind the MVLinear: S.y holds the MVLinear output (without bias).
-// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_row points at this lane's channel row of the block's output in front of
-// its layer norm, stored by the forward - the recompute stops behind linear_right and the normalisation: no linear_left
+// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_row points at this lane's 16 slots of the block's output in front of
+// its layer norm, stored by the forward (pl_store_s) - the recompute stops behind linear_right and the normalisation: no linear_left
 // mix, no geometric product (the most expensive phase at D = 32). The row is requested first and picked up behind the
 // normalisation.
 template <class ALG, class LY, int K, bool SAVED = false>
@@ -508,10 +519,10 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G;
     const float* ldsn = lds + ge.n;
     const int c = ge.c;
-    f4 sv[ALG::D / 4];
+    f4 sv[DL / 4];
     if constexpr (SAVED) {
 #pragma unroll
-        for (int e = 0; e < ALG::D / 4; ++e) sv[e] = pl_ld4(s_row + 4 * e);
+        for (int e = 0; e < DL / 4; ++e) sv[e] = pl_ld4(s_row + 4 * e);
         asm volatile("" ::: "memory");
     }
     if (ge.s == 0) S.y[0] += lds[LY::p_b1(K) + c];
@@ -557,7 +568,8 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     CSMPN_PHASE();
     // steerable geometric product + first-order term (cegnn_utils.py:126-152)
     if constexpr (SAVED) {
-        pl_pick<ALG>(S.s, sv, ge.s, 1.0f);
+#pragma unroll
+        for (int j = 0; j < DL; ++j) S.s[j] = sv[j / 4][j % 4];
     } else {
         pl_weighted_gp<ALG>(L, z, r, lds + LY::p_w(K) + c * ALG::P, ge);
 #pragma unroll
@@ -996,14 +1008,8 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
             PlState<ALG> S;
             float out[DL];
             const bool save_s = io.save_state != 0 && io.save != nullptr;
-            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s rows -> region `region` of the saved buffer
-                tile_sync<VAR_WAVE>();
-                pl_stage<ALG>(sc, S.s, ge, RS, true);
-                tile_sync<VAR_WAVE>();
-                pl_copy_rows(sc, RS, ROW, ge.lane, [&](int r) -> float* {
-                    const long rr = tile * kPlRows + r;
-                    return rr < io.rows ? io.save + ((size_t)region * io.rows + rr) * ROW : nullptr;
-                });
+            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s -> region `region` of the saved buffer, lane order
+                if (valid) pl_store_s<ALG>(io.save + ((size_t)region * io.rows + row) * ROW + cofs + ge.s * DL, S.s);
             };
             mvlinear0(S.y);
             pl_block_tail<ALG, LY, 0>(lds, ge, S, out);
@@ -1068,7 +1074,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
 #pragma unroll
                     for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                     pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
-                    pl_block_tail<ALG, LY, 1, SAVES>(lds, ge, S, unused, io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs);
+                    pl_block_tail<ALG, LY, 1, SAVES>(lds, ge, S, unused, io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs + ge.s * DL);
                     pl_block_backward<ALG, LY, 1>(lds, ge, S, gout, gy, tot1, aWR_1, aWL_1);
                 }
                 pl_wgrad<ALG>(aW1_1, gy, in1);
@@ -1082,7 +1088,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 PlState<ALG> S;
                 float unused[DL];
                 mvlinear0(S.y);
-                pl_block_tail<ALG, LY, 0, SAVES>(lds, ge, S, unused, io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs);
+                pl_block_tail<ALG, LY, 0, SAVES>(lds, ge, S, unused, io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs + ge.s * DL);
                 pl_block_backward<ALG, LY, 0>(lds, ge, S, g1, gy0, tot0, aWR_0, aWL_0);
             }
             CSMPN_PHASE();

@@ -210,12 +210,20 @@ CSMPN_DEV float plw_group_sum(float* lds, int slot, int wave, int q, float v) {
 
 // block forward behind the MVLinear (S.y = MVLinear output without bias); mixing through the exchange buffers.
 // Barriers: every wave of the workgroup executes this function for the same tile.
-template <class ALG, class CF, int K>
+// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_lane = this lane's 16 slots of the block's output in front of its layer
+// norm (pl_store_s in the forward) - no linear_left mix, no geometric product in the recompute (cemlp_pl.hpp).
+template <class ALG, class CF, int K, bool SAVED = false>
 CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& ge, int wave, bool cvalid,
-                              PlState<ALG>& S, float (&out)[PS<ALG>::DL]) {
+                              PlState<ALG>& S, float (&out)[PS<ALG>::DL], const float* s_lane = nullptr) {
     using P = PS<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G, NG = CF::NG;
     const int c = 8 * wave + ge.c;       // channel in the (padded) layer
+    f4 sv[DL / 4];
+    if constexpr (SAVED) {
+#pragma unroll
+        for (int e = 0; e < DL / 4; ++e) sv[e] = pl_ld4(s_lane + 4 * e);
+        asm volatile("" ::: "memory");
+    }
     if (ge.s == 0) S.y[0] += lds[CF::p_b1(K) + c];
     float z[DL];
     static_for<0, GC>([&](auto k) {
@@ -243,7 +251,10 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
     // exchanges, row stores), so all waves have left those reads before any wave gets here
     plw_put<ALG>(xb, wave, ge.lane, z);
     __syncthreads();
-    {
+    if constexpr (SAVED) {
+        plw_mix_loop<ALG>(S.R, tabs + CF::t_WR(K) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                          [&](int ig, float (&zi)[DL]) { plw_get<ALG>(zi, xb, ig, ge.lane); });
+    } else {
         const float* tr = tabs + CF::t_WR(K) + (wave * NG * 16 + ge.n) * 24;
         const float* tl = tabs + CF::t_WL(K) + (wave * NG * 16 + ge.n) * 24;
         f4 ran[6], lan[6];
@@ -278,9 +289,14 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
         static_for<j0, j1>([&](auto jj) { r[decltype(jj)::value] = S.R[decltype(jj)::value] * S.invden[k]; });
     });
     CSMPN_PHASE();
-    pl_weighted_gp<ALG>(L, z, r, lds + CF::p_w(K) + c * ALG::P, ge);
+    if constexpr (SAVED) {
 #pragma unroll
-    for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? L[j] * kInvSqrt2 : 0.f;
+        for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? sv[j / 4][j % 4] : 0.f;
+    } else {
+        pl_weighted_gp<ALG>(L, z, r, lds + CF::p_w(K) + c * ALG::P, ge);
+#pragma unroll
+        for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? L[j] * kInvSqrt2 : 0.f;
+    }
     CSMPN_PHASE();
     float qs = 0.f;
     static_for<0, DL>([&](auto jj) {
@@ -408,6 +424,10 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
                           [&](int j, float (&x)[DL]) { load_chunk(j, x); });
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
+        // CSMPN_FLAG_SAVE_STATE (EGCL stages): the blocks' s -> regions 2, 3 of the saved buffer, lane order (pl_store_s)
+        const bool save_s = CF::NBLK > 1 && MODE != MODE_PLAIN && io.save_state != 0 && io.save != nullptr && valid && cvalid;
+        float* const s_dst = save_s ? io.save + (size_t)row * ROW + (8 * wave + ge.c) * D + ge.s * DL : nullptr;
+        if (save_s) pl_store_s<ALG>(s_dst + (size_t)2 * io.rows * ROW, S.s);
         if constexpr (CF::NBLK > 1) {
             // block-1 input: to the exchange buffer (and to HBM for the backward)
             float* xb1 = lds + CF::x_off(1);
@@ -427,6 +447,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
             plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
                               [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
             plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
+            if (save_s) pl_store_s<ALG>(s_dst + (size_t)3 * io.rows * ROW, S.s);
         }
         if constexpr (MODE == MODE_NODE) {
             if (io.resid) {
@@ -728,7 +749,9 @@ __global__ void __launch_bounds__(64 * kPlReduceSubs) plw_reduce_kernel(const De
 
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
 // backward -> input gradients (scatter / rows). Parameter gradients of block BLK.
-template <class ALG, class CF, int BLK>
+// SAVES: the forward ran with CSMPN_FLAG_SAVE_STATE (regions 2, 3 of the saved buffer hold the blocks' s): a compile-time
+// choice, as in cemlp_pl.hpp / cemlp_cl.hpp.
+template <class ALG, class CF, int BLK, bool SAVES = false>
 __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD : CF::waves_per_simd(CF::WG_PER_CU_BWD)) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -817,7 +840,8 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 __syncthreads();
                 plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
                                   [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
-                plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, unused);
+                plw_block_tail<ALG, CF, 1, SAVES>(lds, tabs, ge, wave, cvalid, S, unused,
+                                                  io.saved + ((size_t)3 * io.rows + lrow) * ROW + cch + ge.s * DL);
                 plw_block_backward<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, gout, gy, tot, aWR, aWL);
             }
             static_for<0, NG>([&](auto ig) {
@@ -886,7 +910,8 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                 plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
                                   [&](int j, float (&x)[DL]) { load_chunk(j, x); });
-                plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, unused);
+                plw_block_tail<ALG, CF, 0, SAVES>(lds, tabs, ge, wave, cvalid, S, unused,
+                                                  io.saved + ((size_t)2 * io.rows + lrow) * ROW + cch + ge.s * DL);
                 plw_block_backward<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, g1, gy0, tot, aWR, aWL);
             }
             static_for<0, NCH0>([&](auto jc) {
