@@ -1213,8 +1213,8 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
     if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) {
         ch += (size_t)blocks[0].out_features;
-        // CSMPN_FLAG_SAVE_STATE (parity-lane kernels, cemlp_pl.hpp / cemlp_plw.hpp): regions 2, 3 = the blocks' outputs in front of their layer norms
-        ch += (size_t)n_blocks * blocks[0].out_features;
+        // CSMPN_FLAG_SAVE_STATE (parity-lane kernels, cemlp_pl.hpp / cemlp_plw.hpp): regions 2 .. 7 = s, y, R of the two blocks
+        ch += (size_t)3 * n_blocks * blocks[0].out_features;
     }
     if (cl_shape(n, blocks, n_blocks)) {
         ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane / channel-MFMA backward likewise

@@ -496,36 +496,55 @@ struct PlSumIdx {
 constexpr int kPlThreads = 64 * kPlWaves;
 CSMPN_DEV void pl_sum_add(float* slot, float v) { *slot = *slot + v; }
 
-// CSMPN_FLAG_SAVE_STATE: a block's output in front of its layer norm is private to these kernels and kept in LANE order -
-// [row][channel][parity][16 slots], 64 contiguous bytes per lane: four 16-byte stores in the forward, four loads in the
-// backward, no staging tile and no pick of the parity's blades.
+// CSMPN_FLAG_SAVE_STATE at D = 32: the forward stores, per block, the three tensors the backward would otherwise recompute
+// through two channel mixes and a geometric product - y (MVLinear output with its bias), R (linear_right output) and s (the
+// block's output in front of its layer norm). These kernels run at 5-10 % of the HBM roofline: the extra rows travel under the
+// arithmetic. The rows are private to these kernels and kept in LANE order - [row][channel][parity][16 slots], 64 contiguous
+// bytes per lane: four 16-byte stores / loads per tensor, no staging tile, no pick of the parity's blades.
+// Regions of the saved buffer (rows x ROW floats each): 0 block-1 inputs, 1 hand-over, 2 + K: s, 4 + K: y, 6 + K: R of block K.
 template <class ALG>
-CSMPN_DEV void pl_store_s(float* p, const float (&sv)[PS<ALG>::DL]) {
+CSMPN_DEV void pl_store_lane(float* p, const float (&sv)[PS<ALG>::DL]) {
     static_assert(PS<ALG>::DL % 4 == 0, "whole 16-byte pieces");
 #pragma unroll
     for (int e = 0; e < PS<ALG>::DL / 4; ++e)
         *reinterpret_cast<f4*>(p + 4 * e) = f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]};
 }
+// p: this lane's slots in region 2 + K; step: floats between regions r and r + 2
+template <class ALG>
+CSMPN_DEV void pl_store_state(float* p, size_t step, const PlState<ALG>& S) {
+    pl_store_lane<ALG>(p, S.s);
+    pl_store_lane<ALG>(p + step, S.y);
+    pl_store_lane<ALG>(p + 2 * step, S.R);
+}
+template <class ALG>
+struct PlSaved {
+    f4 y[PS<ALG>::DL / 4], R[PS<ALG>::DL / 4], s[PS<ALG>::DL / 4];
+    CSMPN_DEV void load(const float* p, size_t step) {
+#pragma unroll
+        for (int e = 0; e < PS<ALG>::DL / 4; ++e) y[e] = pl_ld4(p + step + 4 * e);
+#pragma unroll
+        for (int e = 0; e < PS<ALG>::DL / 4; ++e) R[e] = pl_ld4(p + 2 * step + 4 * e);
+#pragma unroll
+        for (int e = 0; e < PS<ALG>::DL / 4; ++e) s[e] = pl_ld4(p + 4 * e);
+    }
+};
 
 // block forward behind the MVLinear: S.y holds the MVLinear output (without bias).
-// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_row points at this lane's 16 slots of the block's output in front of
-// its layer norm, stored by the forward (pl_store_s) - the recompute stops behind linear_right and the normalisation: no linear_left
-// mix, no geometric product (the most expensive phase at D = 32). The row is requested first and picked up behind the
-// normalisation.
+// SAVED (backward under CSMPN_FLAG_SAVE_STATE): y, R and s come from the forward (sv); what is left of the recompute are the
+// gates, the normalisation's denominators and the layer norm's mean - no channel mix, no geometric product.
 template <class ALG, class LY, int K, bool SAVED = false>
 CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG>& S, float (&out)[PS<ALG>::DL],
-                             const float* s_row = nullptr) {
+                             const PlSaved<ALG>* sv = nullptr) {
     using P = PS<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G;
     const float* ldsn = lds + ge.n;
     const int c = ge.c;
-    f4 sv[DL / 4];
     if constexpr (SAVED) {
 #pragma unroll
-        for (int e = 0; e < DL / 4; ++e) sv[e] = pl_ld4(s_row + 4 * e);
-        asm volatile("" ::: "memory");
+        for (int j = 0; j < DL; ++j) { S.y[j] = sv->y[j / 4][j % 4]; S.R[j] = sv->R[j / 4][j % 4]; S.s[j] = sv->s[j / 4][j % 4]; }
+    } else {
+        if (ge.s == 0) S.y[0] += lds[LY::p_b1(K) + c];
     }
-    if (ge.s == 0) S.y[0] += lds[LY::p_b1(K) + c];
     // MVSiLU (cegnn_utils.py:76-83)
     float z[DL];
     static_for<0, GC>([&](auto k) {
@@ -545,11 +564,12 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     CSMPN_PHASE();
     // linear_right / linear_left (cegnn_utils.py:143-148)
     float L[DL];
+    if constexpr (!SAVED) {
 #pragma unroll
-    for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
-    if constexpr (SAVED) pl_linear<ALG, LY::t_WR(K)>(S.R, z, ldsn);
-    else pl_linear2<ALG, LY::t_WR(K), LY::t_WL(K)>(S.R, L, z, ldsn);
-    if (ge.s == 0) L[0] += lds[LY::p_bL(K) + c];
+        for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
+        pl_linear2<ALG, LY::t_WR(K), LY::t_WL(K)>(S.R, L, z, ldsn);
+        if (ge.s == 0) L[0] += lds[LY::p_bL(K) + c];
+    }
     CSMPN_PHASE();
     // NormalizationLayer on the right operand (cegnn_utils.py:42-51)
     float r[DL];
@@ -567,10 +587,7 @@ CSMPN_DEV void pl_block_tail(const float* lds, const PlGeo<ALG>& ge, PlState<ALG
     });
     CSMPN_PHASE();
     // steerable geometric product + first-order term (cegnn_utils.py:126-152)
-    if constexpr (SAVED) {
-#pragma unroll
-        for (int j = 0; j < DL; ++j) S.s[j] = sv[j / 4][j % 4];
-    } else {
+    if constexpr (!SAVED) {
         pl_weighted_gp<ALG>(L, z, r, lds + LY::p_w(K) + c * ALG::P, ge);
 #pragma unroll
         for (int j = 0; j < DL; ++j) S.s[j] = L[j] * kInvSqrt2;
@@ -887,8 +904,8 @@ CSMPN_DEV void pl_scatter(const float* sc, int rs, int t_add, int t_sub, float* 
 // ---------------------------------------------------------------------------------
 // the kernel. NBLK = 2 blocks of 8 channels; block 0 has I0 input channels.
 // MODE_EDGE: I0 = 8 + A; MODE_NODE: I0 = 16 + T.
-// SAVES (backward): the forward ran with CSMPN_FLAG_SAVE_STATE - regions 2 and 3 behind [block-1 inputs | hand-over] of the
-// saved buffer hold the outputs of block 0 / 1 in front of their layer norms (a compile-time choice, as in cemlp_cl.hpp).
+// SAVES (backward): the forward ran with CSMPN_FLAG_SAVE_STATE - regions 2 .. 7 behind [block-1 inputs | hand-over] of the
+// saved buffer hold s, y, R of block 0 / 1 (pl_store_state; a compile-time choice, as in cemlp_cl.hpp).
 template <class ALG, int MODE, int NBLK, int I0, bool BWD, bool SAVES = false>
 __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMPN_PL_FWD_WAVES) cemlp_pl_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
@@ -1008,8 +1025,8 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
             PlState<ALG> S;
             float out[DL];
             const bool save_s = io.save_state != 0 && io.save != nullptr;
-            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s -> region `region` of the saved buffer, lane order
-                if (valid) pl_store_s<ALG>(io.save + ((size_t)region * io.rows + row) * ROW + cofs + ge.s * DL, S.s);
+            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s, y, R -> regions 2 + K, 4 + K, 6 + K, lane order
+                if (valid) pl_store_state<ALG>(io.save + ((size_t)region * io.rows + row) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW, S);
             };
             mvlinear0(S.y);
             pl_block_tail<ALG, LY, 0>(lds, ge, S, out);
@@ -1071,10 +1088,16 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 {
                     PlState<ALG> S;
                     float unused[DL];
+                    if constexpr (SAVES) {
+                        PlSaved<ALG> sv;
+                        sv.load(io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW);
+                        pl_block_tail<ALG, LY, 1, true>(lds, ge, S, unused, &sv);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-                    pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
-                    pl_block_tail<ALG, LY, 1, SAVES>(lds, ge, S, unused, io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs + ge.s * DL);
+                        for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+                        pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
+                        pl_block_tail<ALG, LY, 1>(lds, ge, S, unused);
+                    }
                     pl_block_backward<ALG, LY, 1>(lds, ge, S, gout, gy, tot1, aWR_1, aWL_1);
                 }
                 pl_wgrad<ALG>(aW1_1, gy, in1);
@@ -1087,8 +1110,14 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
             {
                 PlState<ALG> S;
                 float unused[DL];
-                mvlinear0(S.y);
-                pl_block_tail<ALG, LY, 0, SAVES>(lds, ge, S, unused, io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs + ge.s * DL);
+                if constexpr (SAVES) {
+                    PlSaved<ALG> sv;
+                    sv.load(io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    pl_block_tail<ALG, LY, 0, true>(lds, ge, S, unused, &sv);
+                } else {
+                    mvlinear0(S.y);
+                    pl_block_tail<ALG, LY, 0>(lds, ge, S, unused);
+                }
                 pl_block_backward<ALG, LY, 0>(lds, ge, S, g1, gy0, tot0, aWR_0, aWL_0);
             }
             CSMPN_PHASE();

@@ -210,21 +210,25 @@ CSMPN_DEV float plw_group_sum(float* lds, int slot, int wave, int q, float v) {
 
 // block forward behind the MVLinear (S.y = MVLinear output without bias); mixing through the exchange buffers.
 // Barriers: every wave of the workgroup executes this function for the same tile.
-// SAVED (backward under CSMPN_FLAG_SAVE_STATE): s_lane = this lane's 16 slots of the block's output in front of its layer
-// norm (pl_store_s in the forward) - no linear_left mix, no geometric product in the recompute (cemlp_pl.hpp).
+// SAVED (backward under CSMPN_FLAG_SAVE_STATE): y, R and s come from the forward (pl_store_state / PlSaved, cemlp_pl.hpp): the
+// recompute keeps the gates, the denominators and the layer norm's mean; z still goes to exchange buffer 0 (the weight
+// gradients of linear_left / right read it there).
 template <class ALG, class CF, int K, bool SAVED = false>
 CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& ge, int wave, bool cvalid,
-                              PlState<ALG>& S, float (&out)[PS<ALG>::DL], const float* s_lane = nullptr) {
+                              PlState<ALG>& S, float (&out)[PS<ALG>::DL], const PlSaved<ALG>* sv = nullptr) {
     using P = PS<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G, NG = CF::NG;
     const int c = 8 * wave + ge.c;       // channel in the (padded) layer
-    f4 sv[DL / 4];
     if constexpr (SAVED) {
 #pragma unroll
-        for (int e = 0; e < DL / 4; ++e) sv[e] = pl_ld4(s_lane + 4 * e);
-        asm volatile("" ::: "memory");
+        for (int j = 0; j < DL; ++j) {
+            S.y[j] = cvalid ? sv->y[j / 4][j % 4] : 0.f;
+            S.R[j] = cvalid ? sv->R[j / 4][j % 4] : 0.f;
+            S.s[j] = cvalid ? sv->s[j / 4][j % 4] : 0.f;
+        }
+    } else {
+        if (ge.s == 0) S.y[0] += lds[CF::p_b1(K) + c];
     }
-    if (ge.s == 0) S.y[0] += lds[CF::p_b1(K) + c];
     float z[DL];
     static_for<0, GC>([&](auto k) {
         constexpr int j0 = P::t.cstart[k], j1 = P::t.cstart[k + 1];
@@ -243,18 +247,17 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
     CSMPN_PHASE();
     // linear_right / linear_left over all groups
     float L[DL];
+    if constexpr (!SAVED) {
 #pragma unroll
-    for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
+        for (int j = 0; j < DL; ++j) { S.R[j] = 0.f; L[j] = 0.f; }
+    }
     float* xb = lds + CF::x_off(0);
     // no barrier in front of the put: every earlier reader of buffer 0 (the previous block's / tile's mixing and
     // weight-gradient reads) is followed by a workgroup barrier in program order (LayerNorm exchange, gradient
     // exchanges, row stores), so all waves have left those reads before any wave gets here
     plw_put<ALG>(xb, wave, ge.lane, z);
     __syncthreads();
-    if constexpr (SAVED) {
-        plw_mix_loop<ALG>(S.R, tabs + CF::t_WR(K) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
-                          [&](int ig, float (&zi)[DL]) { plw_get<ALG>(zi, xb, ig, ge.lane); });
-    } else {
+    if constexpr (!SAVED) {
         const float* tr = tabs + CF::t_WR(K) + (wave * NG * 16 + ge.n) * 24;
         const float* tl = tabs + CF::t_WL(K) + (wave * NG * 16 + ge.n) * 24;
         f4 ran[6], lan[6];
@@ -273,7 +276,7 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
             plw_mix2_w<ALG>(S.R, L, zi, ra, la_);
         }
     }
-    if (ge.s == 0) L[0] += lds[CF::p_bL(K) + c];
+    if constexpr (!SAVED) { if (ge.s == 0) L[0] += lds[CF::p_bL(K) + c]; }
     CSMPN_PHASE();
     float r[DL];
     static_for<0, GC>([&](auto k) {
@@ -289,10 +292,7 @@ CSMPN_DEV void plw_block_tail(float* lds, const float* tabs, const PlGeo<ALG>& g
         static_for<j0, j1>([&](auto jj) { r[decltype(jj)::value] = S.R[decltype(jj)::value] * S.invden[k]; });
     });
     CSMPN_PHASE();
-    if constexpr (SAVED) {
-#pragma unroll
-        for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? sv[j / 4][j % 4] : 0.f;
-    } else {
+    if constexpr (!SAVED) {
         pl_weighted_gp<ALG>(L, z, r, lds + CF::p_w(K) + c * ALG::P, ge);
 #pragma unroll
         for (int j = 0; j < DL; ++j) S.s[j] = cvalid ? L[j] * kInvSqrt2 : 0.f;
@@ -424,10 +424,12 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
                           [&](int j, float (&x)[DL]) { load_chunk(j, x); });
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
-        // CSMPN_FLAG_SAVE_STATE (EGCL stages): the blocks' s -> regions 2, 3 of the saved buffer, lane order (pl_store_s)
+        // CSMPN_FLAG_SAVE_STATE (EGCL stages): the blocks' s, y, R -> regions 2 + K, 4 + K, 6 + K of the saved buffer, lane
+        // order (pl_store_state, cemlp_pl.hpp)
         const bool save_s = CF::NBLK > 1 && MODE != MODE_PLAIN && io.save_state != 0 && io.save != nullptr && valid && cvalid;
+        const size_t s_step = (size_t)2 * io.rows * ROW;
         float* const s_dst = save_s ? io.save + (size_t)row * ROW + (8 * wave + ge.c) * D + ge.s * DL : nullptr;
-        if (save_s) pl_store_s<ALG>(s_dst + (size_t)2 * io.rows * ROW, S.s);
+        if (save_s) pl_store_state<ALG>(s_dst + s_step, s_step, S);
         if constexpr (CF::NBLK > 1) {
             // block-1 input: to the exchange buffer (and to HBM for the backward)
             float* xb1 = lds + CF::x_off(1);
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
             plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
                               [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
             plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
-            if (save_s) pl_store_s<ALG>(s_dst + (size_t)3 * io.rows * ROW, S.s);
+            if (save_s) pl_store_state<ALG>(s_dst + s_step + (size_t)io.rows * ROW, s_step, S);
         }
         if constexpr (MODE == MODE_NODE) {
             if (io.resid) {
@@ -749,8 +751,8 @@ __global__ void __launch_bounds__(64 * kPlReduceSubs) plw_reduce_kernel(const De
 
 // BLK = 1: gout -> block-1 backward -> d/d(block-1 input) rows to io.plw_g1.   BLK = 0: io.plw_g1 -> block-0
 // backward -> input gradients (scatter / rows). Parameter gradients of block BLK.
-// SAVES: the forward ran with CSMPN_FLAG_SAVE_STATE (regions 2, 3 of the saved buffer hold the blocks' s): a compile-time
-// choice, as in cemlp_pl.hpp / cemlp_cl.hpp.
+// SAVES: the forward ran with CSMPN_FLAG_SAVE_STATE (regions 2 .. 7 of the saved buffer hold the blocks' s, y, R): a
+// compile-time choice, as in cemlp_pl.hpp / cemlp_cl.hpp.
 template <class ALG, class CF, int BLK, bool SAVES = false>
 __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD : CF::waves_per_simd(CF::WG_PER_CU_BWD)) cemlp_plw_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
@@ -838,10 +840,15 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                 plw_put<ALG>(xb1, wave, ge.lane, in1);
                 __syncthreads();
-                plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
-                                  [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
-                plw_block_tail<ALG, CF, 1, SAVES>(lds, tabs, ge, wave, cvalid, S, unused,
-                                                  io.saved + ((size_t)3 * io.rows + lrow) * ROW + cch + ge.s * DL);
+                if constexpr (SAVES) {
+                    PlSaved<ALG> sv;
+                    sv.load(io.saved + ((size_t)3 * io.rows + lrow) * ROW + cch + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    plw_block_tail<ALG, CF, 1, true>(lds, tabs, ge, wave, cvalid, S, unused, &sv);
+                } else {
+                    plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
+                                      [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
+                    plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, unused);
+                }
                 plw_block_backward<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, gout, gy, tot, aWR, aWL);
             }
             static_for<0, NG>([&](auto ig) {
@@ -908,10 +915,15 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 float unused[DL];
 #pragma unroll
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
-                plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
-                                  [&](int j, float (&x)[DL]) { load_chunk(j, x); });
-                plw_block_tail<ALG, CF, 0, SAVES>(lds, tabs, ge, wave, cvalid, S, unused,
-                                                  io.saved + ((size_t)2 * io.rows + lrow) * ROW + cch + ge.s * DL);
+                if constexpr (SAVES) {
+                    PlSaved<ALG> sv;
+                    sv.load(io.saved + ((size_t)2 * io.rows + lrow) * ROW + cch + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    plw_block_tail<ALG, CF, 0, true>(lds, tabs, ge, wave, cvalid, S, unused, &sv);
+                } else {
+                    plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
+                                      [&](int j, float (&x)[DL]) { load_chunk(j, x); });
+                    plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, unused);
+                }
                 plw_block_backward<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, g1, gy0, tot, aWR, aWL);
             }
             static_for<0, NCH0>([&](auto jc) {
