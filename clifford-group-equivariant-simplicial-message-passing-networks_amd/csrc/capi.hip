@@ -896,7 +896,11 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         if (cm_eligible(id, plan, mode, bwd, io, &channels, &i0)) {
             const long tiles = (io.rows + 15) / 16;   // tile t (16 rows) belongs to wave t % (4 grid)
             const long cap = bwd ? kCmMaxBwdGroups : (channels == 16 ? kCmMaxFwdGroups : 256);   // 32 channels: one workgroup per CU
-            const long groups = (tiles + 3) / 4;
+            // tiles per workgroup and pass: 4 (one per wave), 8 in the 16-channel backward (8-wave workgroups), 2 in the
+            // 32-channel backward (a wave PAIR per tile: with 4 the 59 tiles of an md17 batch's node launch went to 15
+            // workgroups, two tiles after each other per pair, while 241 CUs idled)
+            const long per_group = !bwd ? 4 : (channels == 32 ? 2 : 4);
+            const long groups = (tiles + per_group - 1) / per_group;
             const unsigned grid = (unsigned)(groups < cap ? groups : cap);
             if (bwd) {
                 const size_t pb = cemlp_cm_partial_floats_n3(mode, plan.C.nblk, channels, i0) * sizeof(float) * kCmSliceCap;
@@ -908,8 +912,9 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (debug_cm) fprintf(stderr, "[csmpn] cm mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
             HIP_TRY(launch_cemlp_cm_n3(mode, plan.C.nblk, channels, i0, bwd, grid, st, plan.C, io, &handled));
             if (handled) {
-                note_kernel("csmpn::cemlp_%s_kernel<%s, %d, %d, %d, %d>", !bwd ? "cm_fwd" : (channels == 32 ? "cmp" : "cmb"), alg_name(id), channels,
-                            mode, plan.C.nblk, i0 - (mode == MODE_EDGE ? 1 : 2) * channels);
+                note_kernel("csmpn::cemlp_%s_kernel<%s, %d, %d, %d, %d%s>", !bwd ? "cm_fwd" : (channels == 32 ? "cmp" : "cmb"), alg_name(id), channels,
+                            mode, plan.C.nblk, i0 - (mode == MODE_EDGE ? 1 : 2) * channels,
+                            bwd && channels == 32 ? (io.save_state && plan.C.nblk > 1 ? ", true" : ", false") : "");
                 return CSMPN_OK;
             }
         }
@@ -1222,6 +1227,8 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
         if (has_cemlp_cl_n3(MODE_EDGE, n_blocks, blocks[0].out_features, blocks[0].in_features) ||
             has_cemlp_cl_n3(MODE_NODE, n_blocks, blocks[0].out_features, blocks[0].in_features))
             ch += (size_t)n_blocks * blocks[0].out_features;
+        // ... 32-channel channel-MFMA kernels (cemlp_cm.hpp / cemlp_cmp.hpp): regions 2 .. 7 = s, y, R of the two blocks
+        else if (blocks[0].out_features == 32 && cm_bwd_enabled()) ch += (size_t)3 * n_blocks * 32;
     }
     else if (general_phased_shape(n, blocks, n_blocks)) ch *= 2;               // the general kernels' phased backward: one hand-over slot per saved input
     return ch << n;

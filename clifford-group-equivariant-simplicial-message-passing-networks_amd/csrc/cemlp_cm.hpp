@@ -244,10 +244,26 @@ CSMPN_DEV float cm_gp_tail(const float (&z)[8], const float (&R)[8], float (&L)[
 // sum over the four q (the lanes 16 apart): every lane receives the sum of its row
 CSMPN_DEV float cm_q_sum(float v) { return mfma16(1.0f, v, f4{0.f, 0.f, 0.f, 0.f})[0]; }
 
-// one block forward. x: the block's input chunks; out: its output. ldsa = table base + 4 lane, ldsp = table base + par +
+// CSMPN_FLAG_SAVE_STATE at 32 channels (md17's width: kernels at 8 % of the HBM roofline, one wave per SIMD): the forward
+// stores y (MVLinear output, no bias), R (linear_right output) and s (the block's output in front of its layer norm) of
+// every block, the pair backward (cemlp_cmp.hpp) reads them instead of recomputing two channel mixes and the geometric
+// product. Private rows in LANE order: [row][group m][q][blade][v] - a lane's f4 t[8] is 128 contiguous bytes, no transposition.
+// Regions of the saved buffer (rows x ROW floats): 0 block-1 inputs, 1 hand-over, 2 + K: s, 4 + K: y, 6 + K: R of block K.
+CSMPN_DEV void cm_store_lane(float* p, const f4 (&t)[8]) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) cl_st4(p + 4 * d, t[d]);
+}
+CSMPN_DEV void cm_load_lane(f4 (&t)[8], const float* p) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d) t[d] = cl_ld4(p + 4 * d);
+}
+
+// one block forward. x: the block's input chunks; out: its output. sv (32 channels, CSMPN_FLAG_SAVE_STATE; else null): this
+// lane's 32 floats of group 0 in the block's s region, step = floats between regions r and r + 2. ldsa = table base + 4 lane, ldsp = table base + par +
 // kClParStride * q (the parameter row of this lane's channel (0, 0); channel (m, v) is 16 m + 4 v rows further).
 template <class ALG, int C, class TB>
-CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (&x)[TB::NCH][8], f4 (&out)[TB::MB][8], ClStamp& stamp, int sid) {
+CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (&x)[TB::NCH][8], f4 (&out)[TB::MB][8], ClStamp& stamp, int sid,
+                                 float* sv = nullptr, size_t step = 0) {
     constexpr int D = ALG::D, MB = TB::MB;
     constexpr int GS1 = TB::w1(1, 0, 0) - TB::w1(0, 0, 0), MS1 = MB > 1 ? TB::w1(0, 1, 0) - TB::w1(0, 0, 0) : 0;
     constexpr int GSC = TB::wc(0, 1, 0, 0) - TB::wc(0, 0, 0, 0), MSC = MB > 1 ? TB::wc(0, 0, 1, 0) - TB::wc(0, 0, 0, 0) : 0;
@@ -257,6 +273,12 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
 #pragma unroll
         for (int d = 0; d < D; ++d) y[m][d] = f4{0.f, 0.f, 0.f, 0.f};
     static_for<0, TB::NCH>([&](auto ch) { cm_mix_chunk<ALG, MB, TB::nstep(ch), GS1, MS1>(y, x[ch], ldsa + TB::w1(0, 0, ch)); });
+    if constexpr (C == 32) {
+        if (sv) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + step + 128 * m, y[m]);
+        }
+    }
     stamp(sid);
     f4 z[MB][8];
     static_for<0, MB>([&](auto m) {
@@ -280,6 +302,12 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
         cm_mix_chunk<ALG, MB, 4, GSC, MSC>(R, z[m], ldsa + TB::wc(0, 0, 0, m));
         cm_mix_chunk<ALG, MB, 4, GSC, MSC>(L, z[m], ldsa + TB::wc(1, 0, 0, m));
     });
+    if constexpr (C == 32) {
+        if (sv) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 2 * step + 128 * m, R[m]);
+        }
+    }
     stamp(sid + 2);
     float nlsum = 0.f;
     static_for<0, MB>([&](auto m) {
@@ -293,6 +321,12 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
             CM_FENCE();
         });
     });
+    if constexpr (C == 32) {
+        if (sv) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 128 * m, L[m]);
+        }
+    }
     stamp(sid + 3);
     // MVLayerNorm (cegnn_utils.py:93-96): mean over the C channels of the row
     const float invMn = fast_rcp(__builtin_fmaf(cm_q_sum(nlsum), 1.0f / float(C), kEps));
@@ -499,6 +533,10 @@ __global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp
         // entry hoisted out of the loop and spilled (1.4 KB of scratch per lane)
         asm volatile("" ::: "memory");
         f4 out[MB][8], in1[MB][8];
+        // CSMPN_FLAG_SAVE_STATE (32 channels, two blocks): this lane's slots in region 2 (block 0's s), see cm_store_lane
+        const size_t s_step = (size_t)2 * io.rows * ROW;
+        float* const sv0 = (C == 32 && NBLK > 1 && io.save_state != 0 && io.save != nullptr && T.valid)
+                               ? io.save + ((size_t)2 * io.rows + T.row) * ROW + 32 * q : nullptr;
         {
             f4 x[T0::NCH][8];
             raw.template finish<T0>(x, T);
@@ -506,7 +544,7 @@ __global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             stamp(1);
-            cm_block_forward<ALG, C, T0>(ldsa0, ldsp0, x, out, stamp, 2);
+            cm_block_forward<ALG, C, T0>(ldsa0, ldsp0, x, out, stamp, 2, sv0, s_step);
         }
         if constexpr (NBLK > 1) {
 #pragma unroll
@@ -522,7 +560,7 @@ __global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp
 #pragma unroll
                 for (int m = 0; m < MB; ++m) cm_store_piece(io.save + (size_t)T.row * ROW + (16 * m + q) * D, in1[m]);
             }
-            cm_block_forward<ALG, C, T1>(ldsa1, ldsp1, in1, out, stamp, 8);
+            cm_block_forward<ALG, C, T1>(ldsa1, ldsp1, in1, out, stamp, 8, sv0 ? sv0 + (size_t)io.rows * ROW : nullptr, s_step);
         }
         // next tile's rows, then this tile's stores (edge program: loads queued behind atomics wait for them; the node
         // program has no atomics and asks for its rows after the stores - fewer live registers)

@@ -172,7 +172,10 @@ struct CpIn {
 
 // backward of block K over this pair's tiles. tab: the block's tables; slots: this pair's five slots; red: this pair's
 // 4 x 2 x 16 floats of row sums; work: all slots of the workgroup (the end-of-block image lies over them).
-template <class ALG, int C, int MODE, int NBLK, int NA, int K>
+// SAVES (CSMPN_FLAG_SAVE_STATE): y, R and s of the block come from the forward (cm_store_lane, cemlp_cm.hpp) - the tile
+// starts at the gates; both W1 mixes, the linear_right / left mixes and the product's forward are gone, the input rows are
+// only parked in the slots for d/dW1.
+template <class ALG, int C, int MODE, int NBLK, int NA, int K, bool SAVES>
 __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, float* work, ClStamp& stamp) {
     static_assert(C == 32, "two channel groups");
     using TF = CmTab<C, MODE, NA, K>;
@@ -235,7 +238,12 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
     CmTile<MODE> T;
     T.template load<NA>(io, tile, r);
     CpIn<ALG, C, MODE, NA, K> in;
-    in.issue(io, T, p, q);
+    // SAVES: this lane's 32 floats of group p in the block's s region; y one step, R two steps further
+    const size_t s_step = (size_t)2 * io.rows * ROW;
+    auto state_of = [&](const CmTile<MODE>& t) { return io.saved + ((size_t)(2 + K) * io.rows + t.lrow) * ROW + 128 * p + 32 * q; };
+    f4 ynext[8];   // SAVES: the next tile's y, requested in front of the current tile's stores
+    if constexpr (SAVES) cm_load_lane(ynext, state_of(T) + s_step);
+    else in.issue(io, T, p, q);
     for (long it = 0; it < iters; ++it, tile += tstride) {
         asm volatile("" ::: "memory");
         // ---- the block's input: own half -> XZp (+ attributes -> XA), y = W1 x over all chunks
@@ -274,7 +282,11 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                 mix_w1(1, x1);
             }
         };
-        {
+        const float* const sp = SAVES ? state_of(T) : nullptr;
+        if constexpr (SAVES) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) y[d] = ynext[d];
+        } else {
             f4 x0[8];
             mvlinear(x0, true);
         }
@@ -282,6 +294,11 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         CM_FENCE();
         // ---- forward again: z = gate(y) y; R = WR z, s = (WL z + bL + gp(z, n(R))) / sqrt 2
         f4 z[8], R[8], s[8];
+        if constexpr (SAVES) {       // requested in front of the gates: they travel under them (requesting them a tile ahead,
+            cm_load_lane(s, sp);     // with y, costs 23 AGPRs and 4 % at M32)
+            cm_load_lane(R, sp + 2 * s_step);
+            asm volatile("" ::: "memory");
+        }
         static_for<0, 4>([&](auto v) {
             float yy[D], zz[D], gate[4];
 #pragma unroll
@@ -293,6 +310,10 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             for (int d = 0; d < D; ++d) z[d][int(v)] = zz[d];
             CM_FENCE();
         });
+        if constexpr (SAVES) {
+            cp_put(XZp, lane, z);    // (the last readers of XZ - the previous tile's d/dW1 - are behind the tile's closing rendezvous)
+            pair_sync();
+        } else {
         pair_sync();                 // everybody is done with the input chunks
         cp_put(XZp, lane, z);
         pair_sync();
@@ -306,6 +327,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             cm_mix_one<ALG, 4, GSC>(s, z, ldsa + wce(1, p, p));
             cm_mix_one<ALG, 4, GSC>(s, zo, ldsa + wce(1, p, 1 - p));
         }
+        }
         // d/d(out), own half: it travels under the per-channel product phase
         CM_FENCE();
         CmPiece gp;
@@ -313,7 +335,16 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                 (16 * p + q) * D);
         asm volatile("" ::: "memory");
         float nlsum = 0.f;
-#ifndef CP_X_NOTAIL
+        if constexpr (SAVES) {       // the smooth norms of the saved s rows
+            static_for<0, 4>([&](auto v) {
+                float qs = 0.f;
+                static_for<0, D>([&](auto dd) {
+                    constexpr int d = decltype(dd)::value;
+                    qs += qsf<ALG, d> * s[d][int(v)] * s[d][int(v)];
+                });
+                nlsum += cl_smooth_abs_sqrt(qs);
+            });
+        } else {
         static_for<0, 4>([&](auto v) {
             float zz[D], RR[D], LL[D], invden[4];
 #pragma unroll
@@ -325,7 +356,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             for (int d = 0; d < D; ++d) s[d][int(v)] = LL[d];
             CM_FENCE();
         });
-#endif
+        }
         // mean over the 32 channels: the partner's row sums through red[0]
         const float nl_own = cm_q_sum(nlsum);
         if (q == 0) red[(0 * 2 + p) * 16 + r] = nl_own;
@@ -427,6 +458,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         // the input again (the gates' argument y = W1 x; d/dW1's operand): requested here, it travels under the MFMAs below
         asm volatile("" : "+v"(T.i_dst), "+v"(T.i_src), "+v"(T.i_perm), "+v"(T.lrow));
         in.issue(io, T, p, q);
+        if constexpr (SAVES) cm_load_lane(y, sp + s_step);   // the gates' argument once more (not kept live over the product's backward)
         asm volatile("" ::: "memory");
         pair_sync();
         CPW cp_wgrad2<ALG>(aWR[0], aWR[1], GGp, XZ0, XZ1, lane);
@@ -435,7 +467,15 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         CM_FENCE();
         pair_sync();                 // z and d/dR are no longer read
         f4 x0[8];
-        mvlinear(x0, false);
+        if constexpr (SAVES) {       // the input rows go to the slots for d/dW1 only (XZ: the LAST full-width segment's halves)
+            f4 x1[8], xa[8];
+            in.finish(x0, x1, xa, T);
+            if constexpr (NFULL > 1) cp_put(XZp, lane, x1);
+            else cp_put(XZp, lane, x0);
+            if constexpr (kAttr) { if (p == 0) cp_put(XA, lane, xa); }
+        } else {
+            mvlinear(x0, false);
+        }
         stamp(7); CB_MARK(7);
         CM_FENCE();
 #ifndef CP_X_NOSILU
@@ -490,7 +530,8 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         // the next tile's rows leave in front of this tile's stores / atomics
         const CmTile<MODE> Tc = T;
         T.template load<NA>(io, tile + tstride, r);
-        in.issue(io, T, p, q);
+        if constexpr (SAVES) cm_load_lane(ynext, state_of(T) + s_step);
+        else in.issue(io, T, p, q);
         asm volatile("" ::: "memory");
         const int coff = (16 * p + q) * D;
         if constexpr (K > 0) {
@@ -618,7 +659,7 @@ constexpr size_t cp_lds_bytes() {
     return sizeof(float) * (tabs + (kCpWaves / 2) * (kCpSlots * kCbSlot + 64));
 }
 
-template <class ALG, int C, int MODE, int NBLK, int NA>
+template <class ALG, int C, int MODE, int NBLK, int NA, bool SAVES = false>
 __global__ void __launch_bounds__(64 * kCpWaves, CP_OCC) cemlp_cmp_kernel(const DevCemlp C_arg, const RowIO io_arg) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -639,14 +680,14 @@ __global__ void __launch_bounds__(64 * kCpWaves, CP_OCC) cemlp_cmp_kernel(const 
         cb_stage_block<ALG, C, CmTab<C, MODE, NA, 1>, 64 * kCpWaves>(Cd.b[1], smem, threadIdx.x);
         __syncthreads();
         stamp(0);
-        cp_block<ALG, C, MODE, NBLK, NA, 1>(io, smem, slots, red, work, stamp);
+        cp_block<ALG, C, MODE, NBLK, NA, 1, SAVES>(io, smem, slots, red, work, stamp);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's hand-over rows have left for L2
         __syncthreads();
     }
     cb_stage_block<ALG, C, CmTab<C, MODE, NA, 0>, 64 * kCpWaves>(Cd.b[0], smem, threadIdx.x);
     __syncthreads();
     stamp(0);
-    cp_block<ALG, C, MODE, NBLK, NA, 0>(io, smem, slots, red, work, stamp);
+    cp_block<ALG, C, MODE, NBLK, NA, 0, SAVES>(io, smem, slots, red, work, stamp);
     stamp.flush(io.stamps, threadIdx.x & 63);
 }
 

@@ -29,9 +29,11 @@ CMP_BWD = ["setup(stage tables)", "input -> slots, W1 mix", "r:silu, z->slots, l
            "b:silu, gy->slots, wgrad W1, W1^T", "", "next tile + store/scatter", "waiting at the pair's rendezvous (all phases)", "", "", "", "", "", "end-of-block sums"]
 
 
-def main(workload="S1", family="cl"):
+def main(workload="S1", family="cl", nodes=0, edges=0):
     dev = torch.device("cuda:0")
     metric, C, N, E = bench.WORKLOADS[workload]
+    if nodes and edges:   # the workload's layer shape at another size (e.g. an md17 batch: 940 11266)
+        N, E = nodes, edges
     (h, ei, ea, na), _ = bench.make_inputs(metric, C, N, E, 0, E, dev)
     torch.manual_seed(0)
     layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr="mean").to(dev)
@@ -67,4 +69,5 @@ def main(workload="S1", family="cl"):
                 print(f"   {nm:24s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "S1", sys.argv[2] if len(sys.argv) > 2 else "cl")
+    main(sys.argv[1] if len(sys.argv) > 1 else "S1", sys.argv[2] if len(sys.argv) > 2 else "cl",
+         int(sys.argv[3]) if len(sys.argv) > 4 else 0, int(sys.argv[4]) if len(sys.argv) > 4 else 0)
