@@ -469,6 +469,7 @@ def test_save_state_matches_recompute(pkg, monkeypatch, metric, C, N, E, aggr, f
     dispatch log names the instantiation."""
     from csmpn_hip import native, ops
     D = 1 << len(metric)
+    torch.manual_seed(5)   # the layer's initial weights (Cl(4,1): the conditioning of the layer varies 10x with them)
     layer = pkg.EGCL(pkg.CliffordAlgebra(metric), C, C, C, edge_attr_features=6, node_attr_features=3, aggr=aggr).to(dev())
     h, ei, ea, na = (t.to(dev()) for t in O.synthetic_complex(O.Algebra(list(metric)), N, E, C, seed=9))
     gout = torch.randn(N, C, D, generator=torch.Generator().manual_seed(10)).to(dev())
@@ -476,6 +477,9 @@ def test_save_state_matches_recompute(pkg, monkeypatch, metric, C, N, E, aggr, f
     be, spec = ops.HipBackend, layer.spec()
     csr = ops.get_csr(ei, N)
     pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
+    # atomic-free aggregation: what is left between the two runs is the rounding of the saved against the recomputed values
+    # (with float atomics the Cl(4,1) case moved between 5e-5 and 4e-4 from run to run)
+    monkeypatch.setattr(ops, "_DETERMINISTIC", True)
     for tag, on in (("save", True), ("recompute", False)):
         monkeypatch.setattr(ops, "_SAVE_STATE", on)
         # the four stages on this thread (csmpn_last_kernel is per thread; autograd's backward runs on its own)
@@ -496,9 +500,12 @@ def test_save_state_matches_recompute(pkg, monkeypatch, metric, C, N, E, aggr, f
     assert len(outs["save"]) == len(outs["recompute"]) > 10
     # Cl(4,1): indefinite norms cancel - the float32 yardstick of the same layer is 3e-4 (tests/test_full_size_twin.py)
     tol = 2e-6 if D == 8 else (2e-4 if min(metric) < 0 else 2e-5)
+    worst = 0.0
     for i, (a, b) in enumerate(zip(outs["save"], outs["recompute"])):
         err = relmax(a.detach().cpu().numpy(), b.detach().cpu().numpy())
+        worst = max(worst, err)
         assert err < tol, (i, err, kernels)
+    print(f"save-state vs recompute, {family}: worst relative difference {worst:.2e}")
 
 
 _PHASED_SCRIPT = r"""
