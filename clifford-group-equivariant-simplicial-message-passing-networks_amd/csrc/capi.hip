@@ -1199,39 +1199,50 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
     return CSMPN_OK;
 }
 
-size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows) {
-    if (rows <= 0) return 0;
-    size_t per = csmpn_cemlp_saved_floats_per_row(n, blocks, n_blocks);
-    // the general kernels' hand-over slots (one per saved input: the per-row figure doubles for them) are used by the phased
-    // backward only, and make_plan takes that form only from sw().phased_min_rows rows on (the same switch, read once)
-    if (per && !cl_shape(n, blocks, n_blocks) && !(n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) &&
-        general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows)
-        per /= 2;
-    return per * (size_t)rows;
+// channels (x D floats) per row of the CSMPN_FLAG_SAVE_STATE regions (cemlp_device.hpp: whole row tiles in the kernels' lane
+// order, one region per tensor and block, rows rounded up to 16):
+//   Cl(3,0) 8 channels (cemlp_cl.hpp)                    s of every block
+//   Cl(3,0) 32 channels (cemlp_cm.hpp / cemlp_cmp.hpp)    s, y, R of every block
+//   Cl(5,0) / Cl(4,1), 8 .. 32 channels (cemlp_pl.hpp / cemlp_plw.hpp)   s, y, R of every block, channels padded to groups of 8
+static size_t state_channels(int n, const csmpn_block_params* blocks, int n_blocks) {
+    if (n_blocks != 2) return 0;
+    const size_t ch = (size_t)blocks[0].out_features;
+    if (plw_table_bytes(n, blocks, n_blocks)) return (size_t)3 * n_blocks * ((ch + 7) / 8 * 8);
+    if (cl_shape(n, blocks, n_blocks)) {
+        if (has_cemlp_cl_n3(MODE_EDGE, n_blocks, (int)ch, blocks[0].in_features) || has_cemlp_cl_n3(MODE_NODE, n_blocks, (int)ch, blocks[0].in_features))
+            return (size_t)n_blocks * ch;
+        if (ch == 32 && cm_bwd_enabled()) return (size_t)3 * n_blocks * 32;
+    }
+    return 0;
 }
-
-size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks) {
-    if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
+// channels per row in front of the state regions: the saved block inputs and the hand-over region(s)
+static size_t base_channels(int n, const csmpn_block_params* blocks, int n_blocks) {
     size_t ch = 0;
     for (int k = 0; k + 1 < n_blocks; ++k) ch += (size_t)blocks[k].out_features;
     // wide parity-lane backward (cemlp_plw.hpp): one more [rows, O, D] region behind the saved inputs, the hand-over
     // of d/d(block-1 input) from its block-1 launch to its block-0 launch
-    if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) {
-        ch += (size_t)blocks[0].out_features;
-        // CSMPN_FLAG_SAVE_STATE (parity-lane kernels, cemlp_pl.hpp / cemlp_plw.hpp): regions 2 .. 7 = s, y, R of the two blocks
-        ch += (size_t)3 * n_blocks * blocks[0].out_features;
-    }
-    if (cl_shape(n, blocks, n_blocks)) {
-        ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane / channel-MFMA backward likewise
-        // CSMPN_FLAG_SAVE_STATE (8-channel kernels): one [rows, O, D] region per block for its output in front of the layer norm
-        if (has_cemlp_cl_n3(MODE_EDGE, n_blocks, blocks[0].out_features, blocks[0].in_features) ||
-            has_cemlp_cl_n3(MODE_NODE, n_blocks, blocks[0].out_features, blocks[0].in_features))
-            ch += (size_t)n_blocks * blocks[0].out_features;
-        // ... 32-channel channel-MFMA kernels (cemlp_cm.hpp / cemlp_cmp.hpp): regions 2 .. 7 = s, y, R of the two blocks
-        else if (blocks[0].out_features == 32 && cm_bwd_enabled()) ch += (size_t)3 * n_blocks * 32;
-    }
+    if (n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;
+    if (cl_shape(n, blocks, n_blocks)) ch += (size_t)blocks[0].out_features;   // the (row, channel)-per-lane / channel-MFMA backward likewise
     else if (general_phased_shape(n, blocks, n_blocks)) ch *= 2;               // the general kernels' phased backward: one hand-over slot per saved input
-    return ch << n;
+    return ch;
+}
+
+size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows) {
+    if (rows <= 0 || !blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
+    size_t base = base_channels(n, blocks, n_blocks);
+    // the general kernels' hand-over slots (one per saved input: the per-row figure doubles for them) are used by the phased
+    // backward only, and make_plan takes that form only from sw().phased_min_rows rows on (the same switch, read once)
+    if (base && !cl_shape(n, blocks, n_blocks) && !(n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) &&
+        general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows)
+        base /= 2;
+    const size_t state_rows = (size_t)((rows + 15) & ~(int64_t)15);
+    return ((base * (size_t)rows) << n) + ((state_channels(n, blocks, n_blocks) * state_rows) << n);
+}
+
+// upper bound per row (the state regions hold up to 15 padding rows more: csmpn_cemlp_saved_floats is exact)
+size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks, int n_blocks) {
+    if (!blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
+    return (base_channels(n, blocks, n_blocks) + state_channels(n, blocks, n_blocks)) << n;
 }
 
 size_t csmpn_cemlp_workspace_bytes(int n, const csmpn_block_params* blocks, int n_blocks) {

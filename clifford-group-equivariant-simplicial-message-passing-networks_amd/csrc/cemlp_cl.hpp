@@ -202,6 +202,13 @@ struct ClTab {
 };
 
 // forward state of one block kept for its backward
+// offset of (row, channel)'s first piece inside a state region (CSMPN_FLAG_SAVE_STATE, cemlp_device.hpp): a tile is 64 / C rows
+// = 64 (row, channel) positions; piece e (4 blades) of position l lies at (tile * 2 + e) * 256 + 4 l floats
+template <int C>
+CSMPN_DEV size_t cl_state_off(long row, int c) {
+    constexpr int RPT = 64 / C;
+    return (size_t)(row / RPT) * 512 + 4 * ((int)(row % RPT) * C + c);
+}
 struct ClFwd {
     float y[8], gate[4], R[8], invden[4], s[8];
     float qs, nl, invMn;
@@ -898,9 +905,9 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
             static_assert(C == 8, "experiment: 8 channels");
             if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 0, (size_t)T.row * ROW + c * D, S);
 #endif
-            if (save_s && T.valid) {   // CSMPN_FLAG_SAVE_STATE: s of block 0 -> region 2 behind [block-1 inputs | hand-over]
-                float* ps_ = io.save + ((size_t)2 * io.rows + (size_t)T.row) * ROW + c * D;
-                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 4, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+            if (save_s && T.valid) {   // CSMPN_FLAG_SAVE_STATE: s of block 0 -> its state region (cemlp_device.hpp): whole tiles, two pieces per lane
+                float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 0) + cl_state_off<C>(T.row, c);
+                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 256, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
             }
         }
         if constexpr (NBLK > 1) {
@@ -915,9 +922,9 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 #ifdef CL_X_SAVE
             if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 1, (size_t)T.row * ROW + c * D, S);
 #endif
-            if (save_s && T.valid) {   // ... s of block 1 -> region 3
-                float* ps_ = io.save + ((size_t)3 * io.rows + (size_t)T.row) * ROW + c * D;
-                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 4, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+            if (save_s && T.valid) {   // ... s of block 1
+                float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 1) + cl_state_off<C>(T.row, c);
+                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 256, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
             }
         }
         // next tile's rows, then this tile's stores
@@ -1048,8 +1055,8 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
 #else
             constexpr bool have_s = SAVES;   // compile time: a run-time switch between the two recomputes spills the node program
             if constexpr (have_s) {   // CSMPN_FLAG_SAVE_STATE: the block's output in front of the layer norm, saved by the forward
-                const float* ps_ = io.saved + ((size_t)(2 + K) * (size_t)io.rows + (size_t)Tc.lrow) * ROW + c * D;
-                const f4 a_ = cl_ld4(ps_), b_ = cl_ld4(ps_ + 4);
+                const float* ps_ = io.saved + state_region<ROW, ROW>(io.rows, 0, K) + cl_state_off<C>(Tc.lrow, c);
+                const f4 a_ = cl_ld4(ps_), b_ = cl_ld4(ps_ + 256);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { S.s[i] = a_[i]; S.s[4 + i] = b_[i]; }
             }

@@ -247,19 +247,20 @@ CSMPN_DEV float cm_q_sum(float v) { return mfma16(1.0f, v, f4{0.f, 0.f, 0.f, 0.f
 // CSMPN_FLAG_SAVE_STATE at 32 channels (md17's width: kernels at 8 % of the HBM roofline, one wave per SIMD): the forward
 // stores y (MVLinear output, no bias), R (linear_right output) and s (the block's output in front of its layer norm) of
 // every block, the pair backward (cemlp_cmp.hpp) reads them instead of recomputing two channel mixes and the geometric
-// product. Private rows in LANE order: [row][group m][q][blade][v] - a lane's f4 t[8] is 128 contiguous bytes, no transposition.
-// Regions of the saved buffer (rows x ROW floats): 0 block-1 inputs, 1 hand-over, 2 + K: s, 4 + K: y, 6 + K: R of block K.
+// product. State regions of the saved buffer (cemlp_device.hpp): a 16-row tile of one tensor and channel group is 8 blades
+// x 64 lanes x 16 bytes in lane order (tile slot = 2 tile + group) - no transposition, 1 KB of contiguous memory per instruction.
+// p: blade 0 of this lane.
 CSMPN_DEV void cm_store_lane(float* p, const f4 (&t)[8]) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) cl_st4(p + 4 * d, t[d]);
+    for (int d = 0; d < 8; ++d) cl_st4(p + 256 * d, t[d]);
 }
 CSMPN_DEV void cm_load_lane(f4 (&t)[8], const float* p) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) t[d] = cl_ld4(p + 4 * d);
+    for (int d = 0; d < 8; ++d) t[d] = cl_ld4(p + 256 * d);
 }
 
-// one block forward. x: the block's input chunks; out: its output. sv (32 channels, CSMPN_FLAG_SAVE_STATE; else null): this
-// lane's 32 floats of group 0 in the block's s region, step = floats between regions r and r + 2. ldsa = table base + 4 lane, ldsp = table base + par +
+// one block forward. x: the block's input chunks; out: its output. sv (32 channels, CSMPN_FLAG_SAVE_STATE; else null): blade 0
+// of this lane, group 0, in the block's s region; step = floats from a block's s region to its y region (and from y to R). ldsa = table base + 4 lane, ldsp = table base + par +
 // kClParStride * q (the parameter row of this lane's channel (0, 0); channel (m, v) is 16 m + 4 v rows further).
 template <class ALG, int C, class TB>
 CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (&x)[TB::NCH][8], f4 (&out)[TB::MB][8], ClStamp& stamp, int sid,
@@ -276,7 +277,7 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
     if constexpr (C == 32) {
         if (sv) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) cm_store_lane(sv + step + 128 * m, y[m]);
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + step + 2048 * m, y[m]);
         }
     }
     stamp(sid);
@@ -305,7 +306,7 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
     if constexpr (C == 32) {
         if (sv) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 2 * step + 128 * m, R[m]);
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 2 * step + 2048 * m, R[m]);
         }
     }
     stamp(sid + 2);
@@ -324,7 +325,7 @@ CSMPN_DEV void cm_block_forward(const float* ldsa, const float* ldsp, const f4 (
     if constexpr (C == 32) {
         if (sv) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 128 * m, L[m]);
+            for (int m = 0; m < MB; ++m) cm_store_lane(sv + 2048 * m, L[m]);
         }
     }
     stamp(sid + 3);
@@ -533,10 +534,10 @@ __global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp
         // entry hoisted out of the loop and spilled (1.4 KB of scratch per lane)
         asm volatile("" ::: "memory");
         f4 out[MB][8], in1[MB][8];
-        // CSMPN_FLAG_SAVE_STATE (32 channels, two blocks): this lane's slots in region 2 (block 0's s), see cm_store_lane
-        const size_t s_step = (size_t)2 * io.rows * ROW;
+        // CSMPN_FLAG_SAVE_STATE (32 channels, two blocks): this lane's blade 0 of group 0 in block 0's s region (cm_store_lane)
+        const size_t s_step = (size_t)2 * state_rows(io.rows) * ROW;
         float* const sv0 = (C == 32 && NBLK > 1 && io.save_state != 0 && io.save != nullptr && T.valid)
-                               ? io.save + ((size_t)2 * io.rows + T.row) * ROW + 32 * q : nullptr;
+                               ? io.save + state_region<ROW, ROW>(io.rows, 0, 0) + (size_t)tile * (kCmRows * ROW) + 4 * lane : nullptr;
         {
             f4 x[T0::NCH][8];
             raw.template finish<T0>(x, T);
@@ -560,7 +561,7 @@ __global__ void __launch_bounds__(64 * kCmWaves, C == 16 ? CM_FWD_OCC : 1) cemlp
 #pragma unroll
                 for (int m = 0; m < MB; ++m) cm_store_piece(io.save + (size_t)T.row * ROW + (16 * m + q) * D, in1[m]);
             }
-            cm_block_forward<ALG, C, T1>(ldsa1, ldsp1, in1, out, stamp, 8, sv0 ? sv0 + (size_t)io.rows * ROW : nullptr, s_step);
+            cm_block_forward<ALG, C, T1>(ldsa1, ldsp1, in1, out, stamp, 8, sv0 ? sv0 + state_rows(io.rows) * ROW : nullptr, s_step);
         }
         // next tile's rows, then this tile's stores (edge program: loads queued behind atomics wait for them; the node
         // program has no atomics and asks for its rows after the stores - fewer live registers)

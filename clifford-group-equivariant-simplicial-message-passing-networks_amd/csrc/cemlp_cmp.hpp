@@ -238,9 +238,11 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
     CmTile<MODE> T;
     T.template load<NA>(io, tile, r);
     CpIn<ALG, C, MODE, NA, K> in;
-    // SAVES: this lane's 32 floats of group p in the block's s region; y one step, R two steps further
-    const size_t s_step = (size_t)2 * io.rows * ROW;
-    auto state_of = [&](const CmTile<MODE>& t) { return io.saved + ((size_t)(2 + K) * io.rows + t.lrow) * ROW + 128 * p + 32 * q; };
+    // SAVES: y one step behind s, R two steps
+    const size_t s_step = (size_t)2 * state_rows(io.rows) * ROW;
+    auto state_of = [&](const CmTile<MODE>& t) {   // blade 0 of this lane, group p, in block K's s region (cm_store_lane)
+        return io.saved + state_region<ROW, ROW>(io.rows, 0, K) + ((size_t)(t.lrow >> 4) * 2 + p) * 2048 + 4 * (int)(t.lrow & 15) + 64 * q;
+    };
     f4 ynext[8];   // SAVES: the next tile's y, requested in front of the current tile's stores
     if constexpr (SAVES) cm_load_lane(ynext, state_of(T) + s_step);
     else in.issue(io, T, p, q);

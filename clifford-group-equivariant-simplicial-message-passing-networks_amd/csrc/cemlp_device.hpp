@@ -184,6 +184,18 @@ struct Geo {
 
 template <class ALG, int d> constexpr float qsf = float(ALG::t.qsign[d]);
 
+// ---- CSMPN_FLAG_SAVE_STATE: the state regions of the saved buffer ------------------------------------------------------
+// [rows x ROW block-1 inputs][rows x ROW hand-over][state regions ...]: a state region holds ONE tensor (s, y or R) of ONE
+// block for all rows, as whole row TILES in the owning kernels' lane order - piece e of lane l of a wave's tile lies at
+// ((tile_slot * PIECES + e) * 64 + l) * 4 floats, so one store / load instruction of a wave covers 1 KB of contiguous
+// memory. (The first version kept a lane's pieces contiguous - 16 bytes per lane at a 64 / 128-byte stride, four to eight
+// times the memory transactions: S3 edge forward 212 -> 325 us with the stores, M32 206 -> 299 us.)
+// Region k = 2 t + K (t: 0 s, 1 y, 2 R; K: block) starts at  saved + 2 rows ROW + k * state_rows(rows) * ROWP  (ROWP: the row
+// length with the channels padded to the kernels' lane groups); csmpn_cemlp_saved_floats sizes the buffer accordingly.
+CSMPN_DEV size_t state_rows(long rows) { return (size_t)((rows + 15) & ~15L); }
+template <int ROW, int ROWP>
+CSMPN_DEV size_t state_region(long rows, int t, int K) { return (size_t)2 * rows * ROW + (size_t)(2 * t + K) * state_rows(rows) * ROWP; }
+
 CSMPN_DEV f4 mfma16(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 template <int CTRL>

@@ -499,33 +499,35 @@ CSMPN_DEV void pl_sum_add(float* slot, float v) { *slot = *slot + v; }
 // CSMPN_FLAG_SAVE_STATE at D = 32: the forward stores, per block, the three tensors the backward would otherwise recompute
 // through two channel mixes and a geometric product - y (MVLinear output with its bias), R (linear_right output) and s (the
 // block's output in front of its layer norm). These kernels run at 5-10 % of the HBM roofline: the extra rows travel under the
-// arithmetic. The rows are private to these kernels and kept in LANE order - [row][channel][parity][16 slots], 64 contiguous
-// bytes per lane: four 16-byte stores / loads per tensor, no staging tile, no pick of the parity's blades.
-// Regions of the saved buffer (rows x ROW floats each): 0 block-1 inputs, 1 hand-over, 2 + K: s, 4 + K: y, 6 + K: R of block K.
+// arithmetic. State regions of the saved buffer (cemlp_device.hpp): a wave's 4-row tile of one tensor is 4 pieces x 64 lanes x
+// 16 bytes in lane order - no staging tile, no pick of the parity's blades, every instruction 1 KB of contiguous memory.
+// p: piece 0 of this lane (tile slot * 1024 + 4 lane floats into the region).
 template <class ALG>
 CSMPN_DEV void pl_store_lane(float* p, const float (&sv)[PS<ALG>::DL]) {
-    static_assert(PS<ALG>::DL % 4 == 0, "whole 16-byte pieces");
+    static_assert(PS<ALG>::DL == 16, "four 16-byte pieces per lane");
 #pragma unroll
-    for (int e = 0; e < PS<ALG>::DL / 4; ++e)
-        *reinterpret_cast<f4*>(p + 4 * e) = f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]};
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<f4*>(p + 256 * e) = f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]};
 }
-// p: this lane's slots in region 2 + K; step: floats between regions r and r + 2
-template <class ALG>
-CSMPN_DEV void pl_store_state(float* p, size_t step, const PlState<ALG>& S) {
-    pl_store_lane<ALG>(p, S.s);
-    pl_store_lane<ALG>(p + step, S.y);
-    pl_store_lane<ALG>(p + 2 * step, S.R);
+// base: the saved buffer; off: this lane's offset inside a state region; ROW / ROWP as in state_region()
+template <class ALG, int ROW, int ROWP>
+CSMPN_DEV void pl_store_state(float* base, long rows, int K, size_t off, const PlState<ALG>& S) {
+    pl_store_lane<ALG>(base + state_region<ROW, ROWP>(rows, 0, K) + off, S.s);
+    pl_store_lane<ALG>(base + state_region<ROW, ROWP>(rows, 1, K) + off, S.y);
+    pl_store_lane<ALG>(base + state_region<ROW, ROWP>(rows, 2, K) + off, S.R);
 }
 template <class ALG>
 struct PlSaved {
-    f4 y[PS<ALG>::DL / 4], R[PS<ALG>::DL / 4], s[PS<ALG>::DL / 4];
-    CSMPN_DEV void load(const float* p, size_t step) {
+    f4 y[4], R[4], s[4];
+    template <int ROW, int ROWP>
+    CSMPN_DEV void load(const float* base, long rows, int K, size_t off) {
+        const float *py = base + state_region<ROW, ROWP>(rows, 1, K) + off, *pR = base + state_region<ROW, ROWP>(rows, 2, K) + off,
+                    *ps = base + state_region<ROW, ROWP>(rows, 0, K) + off;
 #pragma unroll
-        for (int e = 0; e < PS<ALG>::DL / 4; ++e) y[e] = pl_ld4(p + step + 4 * e);
+        for (int e = 0; e < 4; ++e) y[e] = pl_ld4(py + 256 * e);
 #pragma unroll
-        for (int e = 0; e < PS<ALG>::DL / 4; ++e) R[e] = pl_ld4(p + 2 * step + 4 * e);
+        for (int e = 0; e < 4; ++e) R[e] = pl_ld4(pR + 256 * e);
 #pragma unroll
-        for (int e = 0; e < PS<ALG>::DL / 4; ++e) s[e] = pl_ld4(p + 4 * e);
+        for (int e = 0; e < 4; ++e) s[e] = pl_ld4(ps + 256 * e);
     }
 };
 
@@ -1025,12 +1027,12 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
             PlState<ALG> S;
             float out[DL];
             const bool save_s = io.save_state != 0 && io.save != nullptr;
-            auto store_s = [&](int region) {   // CSMPN_FLAG_SAVE_STATE: this block's s, y, R -> regions 2 + K, 4 + K, 6 + K, lane order
-                if (valid) pl_store_state<ALG>(io.save + ((size_t)region * io.rows + row) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW, S);
+            auto store_s = [&](int blk) {   // CSMPN_FLAG_SAVE_STATE: this block's s, y, R -> its state regions (tile slot = tile)
+                if (valid) pl_store_state<ALG, ROW, ROW>(io.save, io.rows, blk, (size_t)tile * (kPlRows * ROW) + 4 * ge.lane, S);
             };
             mvlinear0(S.y);
             pl_block_tail<ALG, LY, 0>(lds, ge, S, out);
-            if (save_s) store_s(2);
+            if (save_s) store_s(0);
             if (io.save) {
                 tile_sync<VAR_WAVE>();
                 pl_stage<ALG>(sc, out, ge, RS, true);
@@ -1047,7 +1049,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 pl_linear<ALG, LY::t_W1(1, 0)>(S.y, in1, ldsn);
             }
             pl_block_tail<ALG, LY, 1>(lds, ge, S, out);
-            if (save_s) store_s(3);
+            if (save_s) store_s(1);
             if constexpr (MODE == MODE_NODE) {
                 if (io.resid) {
                     float res[DL];
@@ -1090,7 +1092,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                     float unused[DL];
                     if constexpr (SAVES) {
                         PlSaved<ALG> sv;
-                        sv.load(io.saved + ((size_t)3 * io.rows + lrow) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW);
+                        sv.template load<ROW, ROW>(io.saved, io.rows, 1, (size_t)(valid ? tile : 0) * (kPlRows * ROW) + 4 * ge.lane);
                         pl_block_tail<ALG, LY, 1, true>(lds, ge, S, unused, &sv);
                     } else {
 #pragma unroll
@@ -1112,7 +1114,7 @@ __global__ void __launch_bounds__(64 * kPlWaves, BWD ? CSMPN_PL_BWD_WAVES : CSMP
                 float unused[DL];
                 if constexpr (SAVES) {
                     PlSaved<ALG> sv;
-                    sv.load(io.saved + ((size_t)2 * io.rows + lrow) * ROW + cofs + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    sv.template load<ROW, ROW>(io.saved, io.rows, 0, (size_t)(valid ? tile : 0) * (kPlRows * ROW) + 4 * ge.lane);
                     pl_block_tail<ALG, LY, 0, true>(lds, ge, S, unused, &sv);
                 } else {
                     mvlinear0(S.y);

@@ -425,11 +425,11 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
         // CSMPN_FLAG_SAVE_STATE (EGCL stages): the blocks' s, y, R -> regions 2 + K, 4 + K, 6 + K of the saved buffer, lane
-        // order (pl_store_state, cemlp_pl.hpp)
+        // order, whole tiles (pl_store_state, cemlp_pl.hpp)
         const bool save_s = CF::NBLK > 1 && MODE != MODE_PLAIN && io.save_state != 0 && io.save != nullptr && valid && cvalid;
-        const size_t s_step = (size_t)2 * io.rows * ROW;
-        float* const s_dst = save_s ? io.save + (size_t)row * ROW + (8 * wave + ge.c) * D + ge.s * DL : nullptr;
-        if (save_s) pl_store_state<ALG>(s_dst + s_step, s_step, S);
+        constexpr int ROWP = CP * D;   // a tile slot = (tile, channel group): kPlRows x 8 channels x D floats
+        const size_t s_off = ((size_t)tile * NG + wave) * (kPlRows * 8 * D) + 4 * ge.lane;
+        if (save_s) pl_store_state<ALG, ROW, ROWP>(io.save, io.rows, 0, s_off, S);
         if constexpr (CF::NBLK > 1) {
             // block-1 input: to the exchange buffer (and to HBM for the backward)
             float* xb1 = lds + CF::x_off(1);
@@ -449,7 +449,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
             plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
                               [&](int ig, float (&xi)[DL]) { plw_get<ALG>(xi, xb1, ig, ge.lane); });
             plw_block_tail<ALG, CF, 1>(lds, tabs, ge, wave, cvalid, S, out);
-            if (save_s) pl_store_state<ALG>(s_dst + s_step + (size_t)io.rows * ROW, s_step, S);
+            if (save_s) pl_store_state<ALG, ROW, ROWP>(io.save, io.rows, 1, s_off, S);
         }
         if constexpr (MODE == MODE_NODE) {
             if (io.resid) {
@@ -842,7 +842,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 __syncthreads();
                 if constexpr (SAVES) {
                     PlSaved<ALG> sv;
-                    sv.load(io.saved + ((size_t)3 * io.rows + lrow) * ROW + cch + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    sv.template load<ROW, CP * D>(io.saved, io.rows, 1, ((size_t)(valid ? tile : 0) * NG + wave) * (kPlRows * 8 * D) + 4 * ge.lane);
                     plw_block_tail<ALG, CF, 1, true>(lds, tabs, ge, wave, cvalid, S, unused, &sv);
                 } else {
                     plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(1) + (wave * NG * 16 + ge.n) * 24, CF::PAIR, NG,
@@ -917,7 +917,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
                 if constexpr (SAVES) {
                     PlSaved<ALG> sv;
-                    sv.load(io.saved + ((size_t)2 * io.rows + lrow) * ROW + cch + ge.s * DL, (size_t)2 * io.rows * ROW);
+                    sv.template load<ROW, CP * D>(io.saved, io.rows, 0, ((size_t)(valid ? tile : 0) * NG + wave) * (kPlRows * 8 * D) + 4 * ge.lane);
                     plw_block_tail<ALG, CF, 0, true>(lds, tabs, ge, wave, cvalid, S, unused, &sv);
                 } else {
                     plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,

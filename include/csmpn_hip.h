@@ -67,14 +67,21 @@ extern "C" {
                                        default). Every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
                                        csmpn_egcl_node_forward/backward and csmpn_cemlp_forward/backward, where it only
                                        selects the atomic-free parameter sums. */
-#define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, round 4: the forward ALSO stores every block's
-                                      * output in front of its layer norm ("s", [rows, O, D] per block) behind the saved block
-                                      * inputs and the hand-over region (csmpn_cemlp_saved_floats_per_row counts them), and
-                                      * the backward called with the same flag reads them instead of recomputing
-                                      * linear_left and the geometric product (measured on S1: edge forward +2.5 us, edge
-                                      * backward -6.5 us). Honoured by the Cl(3,0) 8-channel kernels, ignored elsewhere.
-                                      * Only for a saved buffer laid out for exactly the rows of the call (not a slice of
-                                      * a larger one): the regions are addressed by the call's row count. */
+#define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, round 4: the forward ALSO stores, per block,
+                                      * what the backward would otherwise recompute, in "state regions" behind the saved block
+                                      * inputs and the hand-over region (csmpn_cemlp_saved_floats sizes them), and the backward
+                                      * called with the same flag reads them:
+                                      *   Cl(3,0), 8 channels: s = the block's output in front of its layer norm - no linear_left
+                                      *     mix, no geometric product in the recompute (S1: edge forward +2.5 us, edge backward
+                                      *     -6.5 us; y and R as well: measured a wash there);
+                                      *   Cl(3,0), 32 channels and Cl(5,0) / Cl(4,1), 8 .. 32 channels: y (MVLinear output), R
+                                      *     (linear_right output) and s - no channel mix and no geometric product at all in the
+                                      *     recompute; these kernels run at 5-10 % of the HBM roofline, the extra rows travel
+                                      *     under the arithmetic.
+                                      * The state regions are private to the kernels (whole row tiles in the kernels' lane order).
+                                      * Ignored by every other shape. Only for a saved buffer laid out for exactly the rows of the
+                                      * call (csmpn_cemlp_saved_floats(.., rows) floats; not a slice of a larger one): the
+                                      * regions are addressed by the call's row count. */
 
 /* One CEMLP block = Sequential(MVLinear, MVSiLU, SteerableGeometricProductLayer,
  * MVLayerNorm) (cegnn_utils.py:177-207). Pointers in reference layouts. */
@@ -147,7 +154,8 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
  * regions a launch of that size never touches - the general kernels' hand-over region exists only for launches that can
  * take the block-by-block backward (rows >= its threshold, default 4096; CSMPN_PHASED_MIN_ROWS): a 940-row node stage of a
  * multi-block CEMLP of the small algebras pays half. A buffer of this size is valid for forward and backward of that
- * launch; a larger one (the per-row figure) always is. */
+ * launch. The CSMPN_FLAG_SAVE_STATE regions are counted with the rows rounded up to a multiple of 16 (whole row tiles):
+ * for those shapes the result may exceed rows * per-row figure by up to 15 rows of state. */
 size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows);
 
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
