@@ -252,11 +252,12 @@ CSMPN_DEV float cm_q_sum(float v) { return mfma16(1.0f, v, f4{0.f, 0.f, 0.f, 0.f
 // p: blade 0 of this lane.
 CSMPN_DEV void cm_store_lane(float* p, const f4 (&t)[8]) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) cl_st4(p + 256 * d, t[d]);
+    for (int d = 0; d < 8; ++d)   // streaming: read once, by the backward - no business in L2 next to the gathered h rows
+        __builtin_nontemporal_store(t[d], reinterpret_cast<f4*>(p + 256 * d));
 }
 CSMPN_DEV void cm_load_lane(f4 (&t)[8], const float* p) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) t[d] = cl_ld4(p + 256 * d);
+    for (int d = 0; d < 8; ++d) t[d] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + 256 * d));
 }
 
 // one block forward. x: the block's input chunks; out: its output. sv (32 channels, CSMPN_FLAG_SAVE_STATE; else null): blade 0

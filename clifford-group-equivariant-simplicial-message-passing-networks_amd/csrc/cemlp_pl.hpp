@@ -506,7 +506,8 @@ template <class ALG>
 CSMPN_DEV void pl_store_lane(float* p, const float (&sv)[PS<ALG>::DL]) {
     static_assert(PS<ALG>::DL == 16, "four 16-byte pieces per lane");
 #pragma unroll
-    for (int e = 0; e < 4; ++e) *reinterpret_cast<f4*>(p + 256 * e) = f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]};
+    for (int e = 0; e < 4; ++e)   // streaming stores: these rows are read once, by the backward - they should not evict the gathered h rows from L2
+        __builtin_nontemporal_store(f4{sv[4 * e], sv[4 * e + 1], sv[4 * e + 2], sv[4 * e + 3]}, reinterpret_cast<f4*>(p + 256 * e));
 }
 // base: the saved buffer; off: this lane's offset inside a state region; ROW / ROWP as in state_region()
 template <class ALG, int ROW, int ROWP>
@@ -523,11 +524,11 @@ struct PlSaved {
         const float *py = base + state_region<ROW, ROWP>(rows, 1, K) + off, *pR = base + state_region<ROW, ROWP>(rows, 2, K) + off,
                     *ps = base + state_region<ROW, ROWP>(rows, 0, K) + off;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = pl_ld4(py + 256 * e);
+        for (int e = 0; e < 4; ++e) y[e] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(py + 256 * e));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) R[e] = pl_ld4(pR + 256 * e);
+        for (int e = 0; e < 4; ++e) R[e] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(pR + 256 * e));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[e] = pl_ld4(ps + 256 * e);
+        for (int e = 0; e < 4; ++e) s[e] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ps + 256 * e));
     }
 };
 
