@@ -907,7 +907,8 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 #endif
             if (save_s && T.valid) {   // CSMPN_FLAG_SAVE_STATE: s of block 0 -> its state region (cemlp_device.hpp): whole tiles, two pieces per lane
                 float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 0) + cl_state_off<C>(T.row, c);
-                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 256, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+                __builtin_nontemporal_store(f4{S.s[0], S.s[1], S.s[2], S.s[3]}, reinterpret_cast<f4*>(ps_));       // streaming: read once, by the backward
+                __builtin_nontemporal_store(f4{S.s[4], S.s[5], S.s[6], S.s[7]}, reinterpret_cast<f4*>(ps_ + 256));
             }
         }
         if constexpr (NBLK > 1) {
@@ -924,7 +925,8 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
 #endif
             if (save_s && T.valid) {   // ... s of block 1
                 float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 1) + cl_state_off<C>(T.row, c);
-                cl_st4(ps_, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(ps_ + 256, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
+                __builtin_nontemporal_store(f4{S.s[0], S.s[1], S.s[2], S.s[3]}, reinterpret_cast<f4*>(ps_));       // streaming: read once, by the backward
+                __builtin_nontemporal_store(f4{S.s[4], S.s[5], S.s[6], S.s[7]}, reinterpret_cast<f4*>(ps_ + 256));
             }
         }
         // next tile's rows, then this tile's stores
@@ -1056,7 +1058,7 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
             constexpr bool have_s = SAVES;   // compile time: a run-time switch between the two recomputes spills the node program
             if constexpr (have_s) {   // CSMPN_FLAG_SAVE_STATE: the block's output in front of the layer norm, saved by the forward
                 const float* ps_ = io.saved + state_region<ROW, ROW>(io.rows, 0, K) + cl_state_off<C>(Tc.lrow, c);
-                const f4 a_ = cl_ld4(ps_), b_ = cl_ld4(ps_ + 256);
+                const f4 a_ = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ps_)), b_ = __builtin_nontemporal_load(reinterpret_cast<const f4*>(ps_ + 256));
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { S.s[i] = a_[i]; S.s[4 + i] = b_[i]; }
             }
