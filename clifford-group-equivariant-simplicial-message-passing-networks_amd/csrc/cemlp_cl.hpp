@@ -426,64 +426,6 @@ CSMPN_DEV void cl_block_tail(const float* ldsw, const float* ldsp, ClFwd& S, flo
     stamp(sid + 4);
 }
 
-#ifdef CL_X_SAVE
-// EXPERIMENT (round-3 review, item 3a: save instead of recompute; tools/build_variant_cl.sh): the forward stores y (biased
-// MVLinear output), R (linear_right output) and s (block output in front of the layer norm) per block - 96 bytes per
-// (row, channel) - and the backward rebuilds the rest of the block's forward state from them: gates, normalisation
-// denominators, the layer norm's mean. No channel mixing, no geometric product.
-template <class ALG, int C, class TB>
-CSMPN_DEV void cl_block_tail_saved(const float* ldsp, ClFwd& S) {
-    constexpr int D = ALG::D, G = ALG::G;
-    const f4 sa = cl_ld4(ldsp + (TB::par + 4)), sb = cl_ld4(ldsp + (TB::par + 8));
-    const f4 sg = cl_ld4(ldsp + (TB::par + 12));
-    static_for<0, G>([&](auto g) {
-        constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
-        float u, qq = 0.f;
-        if constexpr (g == 0) {
-            u = S.y[0];
-        } else {
-            u = 0.f;
-            static_for<0, nd>([&](auto t) {
-                constexpr int d = d0 + decltype(t)::value;
-                u += qsf<ALG, d> * S.y[d] * S.y[d];
-            });
-        }
-        S.gate[g] = sigmoidf(__builtin_fmaf(sa[int(g)], u, sb[int(g)]));
-        static_for<0, nd>([&](auto t) {
-            constexpr int d = d0 + decltype(t)::value;
-            qq += qsf<ALG, d> * S.R[d] * S.R[d];
-        });
-        const float m = __builtin_fmaf(sg[int(g)], cl_smooth_abs_sqrt(qq) - 1.0f, 1.0f);
-        S.invden[g] = fast_rcp(m + kEps);
-    });
-    float qs = 0.f;
-    static_for<0, D>([&](auto dd) {
-        constexpr int d = decltype(dd)::value;
-        qs += qsf<ALG, d> * S.s[d] * S.s[d];
-    });
-    S.qs = qs;
-    S.nl = cl_smooth_abs_sqrt(qs);
-    S.invMn = fast_rcp(__builtin_fmaf(cl_chan_sum<C>(S.nl), 1.0f / float(C), kEps));
-}
-CSMPN_DEV void cl_xsave_store(float* base, size_t rows, int blk, size_t off, const ClFwd& S) {
-    float* p = base + (size_t)blk * 3 * rows * 64 + off;
-    cl_st4(p, f4{S.y[0], S.y[1], S.y[2], S.y[3]}); cl_st4(p + 4, f4{S.y[4], S.y[5], S.y[6], S.y[7]});
-    p += rows * 64;
-    cl_st4(p, f4{S.R[0], S.R[1], S.R[2], S.R[3]}); cl_st4(p + 4, f4{S.R[4], S.R[5], S.R[6], S.R[7]});
-    p += rows * 64;
-    cl_st4(p, f4{S.s[0], S.s[1], S.s[2], S.s[3]}); cl_st4(p + 4, f4{S.s[4], S.s[5], S.s[6], S.s[7]});
-}
-CSMPN_DEV void cl_xsave_load(const float* base, size_t rows, int blk, size_t off, ClFwd& S) {
-    const float* p = base + (size_t)blk * 3 * rows * 64 + off;
-    f4 a = cl_ld4(p), b = cl_ld4(p + 4);
-    p += rows * 64;
-    f4 c = cl_ld4(p), d = cl_ld4(p + 4);
-    p += rows * 64;
-    f4 e = cl_ld4(p), f = cl_ld4(p + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { S.y[i] = a[i]; S.y[4 + i] = b[i]; S.R[i] = c[i]; S.R[4 + i] = d[i]; S.s[i] = e[i]; S.s[4 + i] = f[i]; }
-}
-#endif
 
 // ---------------------------------------------------------------------------------
 // order of the per-channel parameter gradients in the lane-private running sums
@@ -901,10 +843,6 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
             static_for<0, T0::NP>([&](auto p) { cl_mix<C, T0::period(p), T0::W1(p), kBatch>(S.y, x[p], ldsw0); });
             stamp(2);
             cl_block_tail<ALG, C, T0, kBatch>(ldsw0, ldsp0, S, out, stamp, 3);
-#ifdef CL_X_SAVE
-            static_assert(C == 8, "experiment: 8 channels");
-            if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 0, (size_t)T.row * ROW + c * D, S);
-#endif
             if (save_s && T.valid) {   // CSMPN_FLAG_SAVE_STATE: s of block 0 -> its state region (cemlp_device.hpp): whole tiles, two pieces per lane
                 float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 0) + cl_state_off<C>(T.row, c);
                 __builtin_nontemporal_store(f4{S.s[0], S.s[1], S.s[2], S.s[3]}, reinterpret_cast<f4*>(ps_));       // streaming: read once, by the backward
@@ -920,9 +858,6 @@ __global__ void __launch_bounds__(64 * kClWaves, 4) cemlp_cl_fwd_kernel(const De
             cl_mix<C, C, T1::W1(0), kBatch>(S.y, in1, ldsw1);
             stamp(8);
             cl_block_tail<ALG, C, T1, kBatch>(ldsw1, ldsp1, S, out, stamp, 9);
-#ifdef CL_X_SAVE
-            if (T.valid) cl_xsave_store(const_cast<float*>(io.plw_tabs), (size_t)io.rows, 1, (size_t)T.row * ROW + c * D, S);
-#endif
             if (save_s && T.valid) {   // ... s of block 1
                 float* ps_ = io.save + state_region<ROW, ROW>(io.rows, 0, 1) + cl_state_off<C>(T.row, c);
                 __builtin_nontemporal_store(f4{S.s[0], S.s[1], S.s[2], S.s[3]}, reinterpret_cast<f4*>(ps_));       // streaming: read once, by the backward
@@ -1051,10 +986,6 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
             ClFwd S;
 #pragma unroll
             for (int d = 0; d < D; ++d) S.y[d] = 0.f;
-#ifdef CL_X_SAVE
-            cl_xsave_load(io.plw_tabs, (size_t)io.rows, K, (size_t)Tc.lrow * ROW + c * D, S);
-            cl_block_tail_saved<ALG, C, TB>(ldsp, S);
-#else
             constexpr bool have_s = SAVES;   // compile time: a run-time switch between the two recomputes spills the node program
             if constexpr (have_s) {   // CSMPN_FLAG_SAVE_STATE: the block's output in front of the layer norm, saved by the forward
                 const float* ps_ = io.saved + state_region<ROW, ROW>(io.rows, 0, K) + cl_state_off<C>(Tc.lrow, c);
@@ -1066,7 +997,6 @@ CSMPN_DEV ClCarry cl_bwd_block(const RowIO& io, float* tab, float* work, const C
             stamp(2);
             float unused[D];
             cl_block_tail<ALG, C, TB, 4>(ldsw, ldsp, S, unused, stamp, 3, have_s);
-#endif
             cl_block_backward<ALG, C, TB>(ldsw, ldsp, S, gout, gy, sm, accR, accL, stamp, 8);
         }
         // MVLinear weight gradient: A = gy, B = the pass's input blade

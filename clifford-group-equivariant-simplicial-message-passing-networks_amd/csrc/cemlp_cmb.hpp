@@ -145,12 +145,6 @@ CSMPN_DEV void cb_mix_t(f4 (&acc)[8], const f4 (&x)[8], const float* ldst) {
 template <int NV>
 CSMPN_DEV float cb_rows_sum(float (&x)[NV], int l16) {
     static_assert(NV == 16 || NV == 8 || NV == 4, "values per call");
-#ifdef CM_X_NOBFLY   // timing experiment only (results wrong): no row sums
-    float t = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) t += x[i];
-    return t + float(l16) * 0.f;
-#endif
     const bool b0 = l16 & 1, b1 = l16 & 2, b2 = l16 & 4, b3 = l16 & 8;
     float y[NV / 2];
 #pragma unroll
@@ -395,9 +389,6 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
         }
         return (n >> 3) * tstride + (long)blockIdx.x * kCbWaves + (n & 7);
     };
-#ifdef CM_X_STAGGER   // timing experiment: the younger half of the workgroup starts half a tile later
-    if (wave >= 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
-#endif
     long tile = claim();
     CmTile<MODE> T, Tn;
     T.template load<NA>(io, tile, r);
@@ -505,13 +496,7 @@ __device__ void cb_block(const RowIO& io, float* tab, float* work, int* ctr, ClS
         stamp(3);
         CB_MARK(3);
         // ---- d/d(linear_left weight) = ggp^T z, both operands from the slots
-#ifdef CM_X_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
         cb_wgrad<ALG>(A.wl, Wq, Pq, AD);
-#ifdef CM_X_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         stamp(4);
         CB_MARK(4);
         // ---- geometric product + normalisation backward, per channel: R becomes d/dR, s becomes the product's d/dz

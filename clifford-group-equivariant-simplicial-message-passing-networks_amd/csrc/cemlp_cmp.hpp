@@ -23,11 +23,6 @@
 #pragma once
 #include "cemlp_cmb.hpp"
 
-#ifdef CP_X_NOWGRAD
-#define CPW if (false)
-#else
-#define CPW
-#endif
 namespace csmpn {
 
 constexpr int kCpWaves = 4;        // waves per workgroup: two pairs, one wave per SIMD
@@ -411,7 +406,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         stamp(3); CB_MARK(3);
         CM_FENCE();
         // ---- d/d(linear_left weight)[group p][group m] = ggp_p^T z_m; d/dz = WL^T ggp (both groups' ggp)
-        CPW cp_wgrad2<ALG>(aWL[0], aWL[1], GGp, XZ0, XZ1, lane);
+        cp_wgrad2<ALG>(aWL[0], aWL[1], GGp, XZ0, XZ1, lane);
         f4 gz[8];
 #pragma unroll
         for (int d = 0; d < D; ++d) gz[d] = f4{0.f, 0.f, 0.f, 0.f};
@@ -425,7 +420,6 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         mix_t(1, ggp);
         stamp(4); CB_MARK(4);
         CM_FENCE();
-#ifndef CP_X_NOGP
         // ---- geometric product + normalisation backward, per channel: R becomes d/dR
         {
             CbCollect<1> col;
@@ -438,13 +432,9 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                     RR[d] = R[d][int(v)];
                 }
                 cp_pin8(RR);
-#ifdef CP_X_NOCOL
-                cb_gp_bwd<ALG>(gg, zf, RR, gzz, gRR, PP(v), [&](auto k, float val) { sm[1] += val; });
-#else
                 cb_gp_bwd<ALG, true>(gg, zf, RR, gzz, gRR, PP(v), [&](auto k, float val) {
                     col.template add<24 * decltype(v)::value + decltype(k)::value>(val, sm, r);
                 });
-#endif
                 cp_pin8(gzz); cp_pin8(gRR);
 #pragma unroll
                 for (int d = 0; d < D; ++d) { gz[d][int(v)] += gzz[d]; R[d][int(v)] = gRR[d]; }
@@ -452,7 +442,6 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
                 CM_FENCE();
             });
         }
-#endif
         stamp(5); CB_MARK(5);
         CM_FENCE();
         pair_sync();                 // everybody is done with ggp in GG
@@ -463,7 +452,7 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         if constexpr (SAVES) cm_load_lane(y, sp + s_step);   // the gates' argument once more (not kept live over the product's backward)
         asm volatile("" ::: "memory");
         pair_sync();
-        CPW cp_wgrad2<ALG>(aWR[0], aWR[1], GGp, XZ0, XZ1, lane);
+        cp_wgrad2<ALG>(aWR[0], aWR[1], GGp, XZ0, XZ1, lane);
         mix_t(0, R);
         stamp(6); CB_MARK(6);
         CM_FENCE();
@@ -480,7 +469,6 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
         }
         stamp(7); CB_MARK(7);
         CM_FENCE();
-#ifndef CP_X_NOSILU
         // ---- MVSiLU backward: gz becomes d/dy
         {
             CbCollect<7> col;
@@ -504,18 +492,17 @@ __device__ void cp_block(const RowIO& io, float* tab, float* slots, float* red, 
             });
             sm[9] += cb_rows_sum<4>(tail, r);
         }
-#endif
         // ---- d/dy through the slots: d/dW1 against the input chunks in XZ / XA, d/d(input)
         cp_put(GGp, lane, gz);
         pair_sync();
         if constexpr (NFULL > 1) {   // node program: XZ holds the aggregate's halves; the first segment follows
-            CPW cp_wgrad2<ALG>(aW1[2], aW1[3], GGp, XZ0, XZ1, lane);
+            cp_wgrad2<ALG>(aW1[2], aW1[3], GGp, XZ0, XZ1, lane);
             pair_sync();
             cp_put(XZp, lane, x0);
             pair_sync();
         }
-        CPW cp_wgrad2<ALG>(aW1[0], aW1[1], GGp, XZ0, XZ1, lane);
-        if constexpr (kAttr) CPW cp_wgrad<ALG>(aW1[NCH - 1], GGp, XA, lane);
+        cp_wgrad2<ALG>(aW1[0], aW1[1], GGp, XZ0, XZ1, lane);
+        if constexpr (kAttr) cp_wgrad<ALG>(aW1[NCH - 1], GGp, XA, lane);
         // d/d(input): wave p emits the chunk p of every full-width segment: gx = sum over the gradient's groups W1^T gy
         f4 gyo[8];
         cp_get(GGo, lane, gyo);

@@ -237,9 +237,6 @@ CSMPN_DEV void pl_linear2(float (&accA)[PS<ALG>::DL], float (&accB)[PS<ALG>::DL]
 template <class ALG>
 CSMPN_DEV void pl_wgrad(f4 (&acc)[PS<ALG>::GC], const float (&g)[PS<ALG>::DL], const float (&x)[PS<ALG>::DL]) {
     using P = PS<ALG>;
-#ifdef PL_X_NOWG
-    acc[0][0] += g[0] * x[0]; return;
-#endif
     static_for<0, P::DL>([&](auto jj) {
         constexpr int j = decltype(jj)::value;
         acc[P::t.cls[j]] = mfma16(g[j], x[j], acc[P::t.cls[j]]);
@@ -654,9 +651,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
         float gwA[P::QP], gwB[P::QP];
 #pragma unroll
         for (int q = 0; q < P::QP; ++q) { gwA[q] = 0.f; gwB[q] = 0.f; }
-#ifndef PL_X_NOGPB
         pl_weighted_gp_bwd_z<ALG>(ggp, S, lds + LY::p_w(K) + c * ALG::P, ge, gz, gwA, gwB);
-#endif
 #pragma unroll
         for (int q = 0; q < P::QP; ++q) {
             pl_sum_add(tot + (SI::wA + q) * kPlThreads, gwA[q]);
@@ -665,11 +660,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
     }
     CSMPN_PHASE();
     float gr[DL];
-#ifndef PL_X_NOGPB
     pl_weighted_gp_bwd_r<ALG>(ggp, S, lds + LY::p_w(K) + c * ALG::P, ge, gr);
-#else
-    for (int j = 0; j < DL; ++j) gr[j] = ggp[j];
-#endif
     CSMPN_PHASE();
     // ---- NormalizationLayer backward -> gR
     float gR[DL];
@@ -873,9 +864,6 @@ CSMPN_DEV void pl_copy_rows(const float* sc, int rs, int ncol, int lane, F&& out
 // and, when SUB, subtraction from table[t_sub[row]]. Negative targets are skipped. t_* live in lane 16 r of row r.
 template <int ROWLEN, bool SUB>
 CSMPN_DEV void pl_scatter(const float* sc, int rs, int t_add, int t_sub, float* table, int lane) {
-#ifdef PL_X_NOSCAT
-    return;
-#endif
     static_for<0, ROWLEN / 64>([&](auto cc) {
         const int col = 64 * decltype(cc)::value + lane;
         float val[kPlRows];
