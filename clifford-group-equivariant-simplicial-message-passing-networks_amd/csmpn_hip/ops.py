@@ -264,10 +264,13 @@ class _EmbedCemlpFn(torch.autograd.Function):
         ws = binding.workspace(vertex_feat.device)
         need_grad = any(ctx.needs_input_grad[4:])
         saved = binding.new_saved(rows, vertex_feat.device) if need_grad else None
+        # the layer's own saved buffer, sized for exactly these rows: CSMPN_FLAG_SAVE_STATE (two-block modules: y, R, s)
+        st_flag = native.FLAG_SAVE_STATE if (_SAVE_STATE and saved is not None and binding.nblk > 1) else 0
         check(native.lib().csmpn_embed_cemlp_forward(
             binding.metric_arr, binding.n, binding.params, binding.nblk, vertex_feat.data_ptr(), int(vertex_feat.shape[1]),
             verts.data_ptr(), int(verts.shape[1]), int(n_orders), rows, out.data_ptr(), _ptr(saved), ws.data_ptr(), ws.numel(),
-            0, _stream(vertex_feat.device)))
+            st_flag, _stream(vertex_feat.device)))
+        ctx.st_flag = st_flag
         global _EMBED_LAUNCHES
         _EMBED_LAUNCHES += 1
         ctx.binding, ctx.param_refs, ctx.ws, ctx.saved, ctx.n_orders = binding, params, ws, saved, int(n_orders)
@@ -289,7 +292,7 @@ class _EmbedCemlpFn(torch.autograd.Function):
         check(native.lib().csmpn_embed_cemlp_backward(
             binding.metric_arr, binding.n, binding.params, binding.grads, binding.nblk, vertex_feat.data_ptr(),
             int(vertex_feat.shape[1]), verts.data_ptr(), int(verts.shape[1]), ctx.n_orders, int(verts.shape[0]),
-            gout.data_ptr(), _ptr(ctx.saved), ctx.ws.data_ptr(), ctx.ws.numel(), 0, _stream(vertex_feat.device)))
+            gout.data_ptr(), _ptr(ctx.saved), ctx.ws.data_ptr(), ctx.ws.numel(), ctx.st_flag, _stream(vertex_feat.device)))
         return (None, None, None, None, *views)
 
 

@@ -1346,7 +1346,7 @@ int csmpn_embed_cemlp_forward(const float* metric, int n, const csmpn_block_para
     int channels = 0, attr = 0;
     if (!plw_eligible(id, plan, MODE_PLAIN, false, io, &channels, &attr))
         return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: shape not served by the wide parity-lane kernels");
-    (void)flags;
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;   // two-block modules: y, R, s of the blocks (as the EGCL stages)
     return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream, false);
 }
 
@@ -1365,7 +1365,7 @@ int csmpn_embed_cemlp_backward(const float* metric, int n, const csmpn_block_par
     int channels = 0, attr = 0;
     if (!plw_eligible(id, plan, MODE_PLAIN, true, io, &channels, &attr))
         return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: shape not served by the wide parity-lane kernels (two blocks need saved inputs)");
-    (void)flags;
+    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, false);
 }
 

@@ -424,9 +424,9 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
                           [&](int j, float (&x)[DL]) { load_chunk(j, x); });
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
-        // CSMPN_FLAG_SAVE_STATE (EGCL stages): the blocks' s, y, R -> regions 2 + K, 4 + K, 6 + K of the saved buffer, lane
+        // CSMPN_FLAG_SAVE_STATE (EGCL stages, fused two-block embedding): the blocks' s, y, R -> regions 2 + K, 4 + K, 6 + K of the saved buffer, lane
         // order, whole tiles (pl_store_state, cemlp_pl.hpp)
-        const bool save_s = CF::NBLK > 1 && MODE != MODE_PLAIN && io.save_state != 0 && io.save != nullptr && valid && cvalid;
+        const bool save_s = CF::NBLK > 1 && io.save_state != 0 && io.save != nullptr && valid && cvalid;
         constexpr int ROWP = CP * D;   // a tile slot = (tile, channel group): kPlRows x 8 channels x D floats
         const size_t s_off = ((size_t)tile * NG + wave) * (kPlRows * 8 * D) + 4 * ge.lane;
         if (save_s) pl_store_state<ALG, ROW, ROWP>(io.save, io.rows, 0, s_off, S);

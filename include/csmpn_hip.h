@@ -67,7 +67,8 @@ extern "C" {
                                        default). Every other shape returns CSMPN_ERR_UNSUPPORTED. Also accepted by
                                        csmpn_egcl_node_forward/backward and csmpn_cemlp_forward/backward, where it only
                                        selects the atomic-free parameter sums. */
-#define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, round 4: the forward ALSO stores, per block,
+#define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, csmpn_embed_cemlp_{forward,backward} (two-block
+                                      * modules), round 4: the forward ALSO stores, per block,
                                       * what the backward would otherwise recompute, in "state regions" behind the saved block
                                       * inputs and the hand-over region (csmpn_cemlp_saved_floats sizes them), and the backward
                                       * called with the same flag reads them:
