@@ -132,6 +132,20 @@ def type_embedding(table: nn.Embedding, types: torch.Tensor) -> torch.Tensor:
     return table.weight.index_select(0, types)
 
 
+def embedded_type_attributes(algebra: CliffordAlgebra, table: nn.Embedding, batch, max_dim: int = 2):
+    """embed_simplex_types of the models with a learned type embedding (md17_cssmpnn.py:122-133): node_attr [S, K, D] and
+    edge_attr [E, 2 K, D]. On the device one launch each way (csmpn_type_attr_*); the index tables are cached on the batch."""
+    ei = batch.edge_index
+    if table.weight.is_cuda and table.weight.dtype == torch.float32:
+        from csmpn_hip import ops
+        plan = batch.plan(max_dim)
+        if "types_i32" not in plan:
+            plan["types_i32"] = batch.node_types.to(torch.int32).contiguous()
+            plan["ei_i32"] = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous())
+        return ops.type_attr_apply(table.weight, plan["types_i32"], plan["ei_i32"][0], plan["ei_i32"][1], algebra.dim)
+    return type_attributes(algebra, type_embedding(table, batch.node_types), ei)
+
+
 class HullsSimplicialMPNN(nn.Module):
     def __init__(self, in_features=1, hidden_features=28, out_features=1, num_layers=3, normalization_init=0,
                  residual=True, aggr="mean", condition=True, max_dim: int = 2):
@@ -210,7 +224,7 @@ class MD17SimplicialMPNN(nn.Module):
         per_graph = segment_mean(loc_node.reshape(-1, F_ * 3), plan["graph_of_vertex"], B).reshape(B, F_, 3)
         per_graph = per_graph.mean(dim=1, keepdim=True).expand(B, F_, 3)
         pos = batch.loc - per_graph[batch.x_ind_batch]
-        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
+        node_attr, edge_attr = embedded_type_attributes(self.algebra, self.sim_type_embedding, batch, self.max_dim)
         x = self._embed(batch, [(pos, 1), (batch.vel, 1), (batch.charges, 0)])
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:
@@ -256,7 +270,7 @@ class MotionSimplicialMPNN(nn.Module):
         # positions relative to the mean vertex position of their graph (motion_cssmpnn.py:139-144)
         mean = segment_mean(node_pos, plan["graph_of_vertex"], B)
         pos = batch.pos.index_copy(0, vr, node_pos - mean[plan["graph_of_vertex"]])
-        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
+        node_attr, edge_attr = embedded_type_attributes(self.algebra, self.sim_type_embedding, batch, self.max_dim)
         x = self._embed(batch, [(pos.unsqueeze(1), 1), (batch.vel.unsqueeze(1), 1)])
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
@@ -312,7 +326,7 @@ class NBASimplicialMPNN(nn.Module):
         F_ = batch.pos.shape[1]
         plan = batch.plan(self.max_dim)
         vr = plan["vertex_rows"]
-        node_attr, edge_attr = type_attributes(self.algebra, type_embedding(self.sim_type_embedding, batch.node_types), batch.edge_index)
+        node_attr, edge_attr = embedded_type_attributes(self.algebra, self.sim_type_embedding, batch, self.max_dim)
         x = self.embed(batch, batch.pos, batch.vel)
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:

@@ -50,6 +50,8 @@ EXPORTS = (
     "csmpn_simplex_rows",
     "csmpn_embed_cemlp_forward",
     "csmpn_embed_cemlp_backward",
+    "csmpn_type_attr_forward",
+    "csmpn_type_attr_backward",
     "csmpn_readout_mse_forward",
     "csmpn_readout_mse_backward",
     "csmpn_last_error",
@@ -133,6 +135,8 @@ def _load():
     sig("csmpn_simplex_rows", C.c_int, [C.c_int, C.POINTER(VertexBlock), C.c_int, vp, i64, i32, i64, vp, vp])
     sig("csmpn_embed_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_embed_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_type_attr_forward", C.c_int, [C.c_int, vp, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp])
+    sig("csmpn_type_attr_backward", C.c_int, [C.c_int, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp])
     sig("csmpn_readout_mse_forward", C.c_int, [C.c_int, vp, vp, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp])
     sig("csmpn_readout_mse_backward", C.c_int, [C.c_int, vp, i32, i64, i32, vp, i64, vp, vp, vp])
     sig("csmpn_last_error", C.c_char_p, [])

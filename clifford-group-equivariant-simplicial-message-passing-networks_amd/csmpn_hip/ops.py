@@ -973,6 +973,48 @@ def simplex_rows(n: int, blocks, verts: torch.Tensor) -> torch.Tensor:
     return out
 
 
+class _TypeAttrFn(torch.autograd.Function):
+    """(node_attr [S, K, D], edge_attr [E, 2 K, D]) from a table of per-type features through csmpn_type_attr_* (one launch
+    each way). table [T, K] float32; types [S], src / dst [E] int32 (constants of the batch)."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, table, types, src, dst, n):
+        _require_device(table, "type-attribute table")
+        tab = table.contiguous()
+        T, K = tab.shape
+        S, E, D = int(types.shape[0]), int(src.shape[0]), 1 << n
+        node_attr = torch.empty(S, K, D, dtype=torch.float32, device=tab.device)
+        edge_attr = torch.empty(E, 2 * K, D, dtype=torch.float32, device=tab.device)
+        check(native.lib().csmpn_type_attr_forward(n, tab.data_ptr(), T, K, types.data_ptr(), S, src.data_ptr(), dst.data_ptr(), E,
+                                                   node_attr.data_ptr(), edge_attr.data_ptr(), _stream(tab.device)))
+        ctx.save_for_backward(types, src, dst)
+        ctx.dims = (n, T, K)
+        ctx.table_ref = table if table.is_contiguous() else None
+        return node_attr, edge_attr
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, g_node, g_edge):
+        types, src, dst = ctx.saved_tensors
+        n, T, K = ctx.dims
+        if not ctx.needs_input_grad[0] or (g_node is None and g_edge is None):
+            return None, None, None, None, None
+        g_node = g_node.contiguous() if g_node is not None else None
+        g_edge = g_edge.contiguous() if g_edge is not None else None
+        ref = ctx.table_ref
+        fuse = ref is not None and _fusable([ref], types.device)
+        g_tab = ref.grad if fuse else torch.zeros(T, K, dtype=torch.float32, device=types.device)
+        check(native.lib().csmpn_type_attr_backward(n, T, K, types.data_ptr(), int(types.shape[0]), src.data_ptr(), dst.data_ptr(),
+                                                    int(src.shape[0]), _ptr(g_node), _ptr(g_edge), g_tab.data_ptr(),
+                                                    _stream(types.device)))
+        return (None if fuse else g_tab), None, None, None, None
+
+
+def type_attr_apply(table, types_i32, src_i32, dst_i32, n):
+    return _TypeAttrFn.apply(table, types_i32, src_i32, dst_i32, int(n))
+
+
 def _binom(n, k):
     import math
     return math.comb(n, k)

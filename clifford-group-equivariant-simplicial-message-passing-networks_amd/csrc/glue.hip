@@ -5,7 +5,12 @@
 //   csmpn_readout_mse_forward / _backward
 //                               scalar readout + loss of the hulls model: MVLinear -> blade 0 -> mean over
 //                               the simplices of a graph -> squared error (hulls_cssmpnn.py:93,155-164)
-// HBM-bound gathers / reductions: one pass over the data, coalesced rows, fixed-order sums (no atomics).
+//   csmpn_type_attr_forward / _backward
+//                               node / edge attributes of the task models from a learned (or one-hot) table of simplex-type
+//                               features (md17_cssmpnn.py:122-133, hulls_cssmpnn.py:127-140): one launch each way instead
+//                               of ~20 small PyTorch launches per step
+// HBM-bound gathers / reductions: one pass over the data, coalesced rows, fixed-order sums (no atomics; the 9-element
+// table gradient of csmpn_type_attr_backward is the exception: block sums in LDS, then one float atomic per element and block).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -108,6 +113,47 @@ __global__ void readout_bwd_kernel(const float* w, int wstride, int C, int D, co
     gx[t] = v;
 }
 
+// one thread per (row, k): row < n_nodes -> node_attr[row][k][:], else edge e = row - n_nodes -> edge_attr[e][k][:] and
+// edge_attr[e][K + k][:]; blade 0 = the table entry, the other blades 0
+__global__ void type_attr_fwd_kernel(const float* table, int K, const int* types, long n_nodes, const int* src, const int* dst,
+                                     long n_edges, int D, float* node_attr, float* edge_attr) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = t / K;
+    const int k = (int)(t % K);
+    if (row >= n_nodes + n_edges) return;
+    auto put = [&](float* p, float v) {
+        p[0] = v;
+        for (int d = 1; d < D; ++d) p[d] = 0.f;
+    };
+    if (row < n_nodes) {
+        put(node_attr + (row * K + k) * D, table[types[row] * K + k]);
+    } else {
+        const long e = row - n_nodes;
+        put(edge_attr + (e * 2 * K + k) * D, table[types[src[e]] * K + k]);
+        put(edge_attr + (e * 2 * K + K + k) * D, table[types[dst[e]] * K + k]);
+    }
+}
+// g_table[t][k] += sum of the blade-0 gradients of every attribute row that read table[t][k]
+constexpr int kTypeBins = 64;   // n_types * K
+__global__ void __launch_bounds__(256) type_attr_bwd_kernel(int K, int TK, const int* types, long n_nodes, const int* src, const int* dst,
+                                                            long n_edges, int D, const float* g_node, const float* g_edge, float* g_table) {
+    __shared__ float bins[kTypeBins];
+    if (threadIdx.x < kTypeBins) bins[threadIdx.x] = 0.f;
+    __syncthreads();
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long row = t / K;
+    const int k = (int)(t % K);
+    if (row < n_nodes) {
+        if (g_node) atomicAdd(&bins[types[row] * K + k], g_node[(row * K + k) * D]);
+    } else if (row < n_nodes + n_edges && g_edge) {
+        const long e = row - n_nodes;
+        atomicAdd(&bins[types[src[e]] * K + k], g_edge[(e * 2 * K + k) * D]);
+        atomicAdd(&bins[types[dst[e]] * K + k], g_edge[(e * 2 * K + K + k) * D]);
+    }
+    __syncthreads();
+    if (threadIdx.x < TK && bins[threadIdx.x] != 0.f) atomicAdd(g_table + threadIdx.x, bins[threadIdx.x]);
+}
+
 int grade_start(int n, int g) {
     int s = 0, c = 1;
     for (int i = 0; i < g; ++i) { s += c; c = c * (n - i) / (i + 1); }
@@ -177,6 +223,37 @@ int csmpn_readout_mse_backward(int n, const float* weight, int32_t weight_stride
                        (long)n_rows, gx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "readout backward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_type_attr_forward(int n, const float* table, int32_t n_types, int32_t k, const int32_t* types, int64_t n_nodes,
+                            const int32_t* src, const int32_t* dst, int64_t n_edges, float* node_attr, float* edge_attr, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_nodes < 0 || n_edges < 0 || k < 1 || n_types < 1 || n_types * k > kTypeBins) return csmpn_fail(CSMPN_ERR_INVALID, "type attributes: bad sizes");
+    if (n_nodes + n_edges == 0) return CSMPN_OK;
+    if (!table || !types || (n_nodes && !node_attr) || (n_edges && (!src || !dst || !edge_attr)))
+        return csmpn_fail(CSMPN_ERR_INVALID, "type attributes: null pointer");
+    const long total = (long)(n_nodes + n_edges) * k;
+    hipLaunchKernelGGL(type_attr_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)k,
+                       (const int*)types, (long)n_nodes, (const int*)src, (const int*)dst, (long)n_edges, 1 << n, node_attr, edge_attr);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "type attributes forward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_type_attr_backward(int n, int32_t n_types, int32_t k, const int32_t* types, int64_t n_nodes, const int32_t* src,
+                             const int32_t* dst, int64_t n_edges, const float* g_node_attr, const float* g_edge_attr, float* g_table,
+                             void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_nodes < 0 || n_edges < 0 || k < 1 || n_types < 1 || n_types * k > kTypeBins) return csmpn_fail(CSMPN_ERR_INVALID, "type attributes: bad sizes");
+    if (n_nodes + n_edges == 0 || (!g_node_attr && !g_edge_attr)) return CSMPN_OK;
+    if (!types || !g_table || (n_edges && g_edge_attr && (!src || !dst))) return csmpn_fail(CSMPN_ERR_INVALID, "type attributes: null pointer");
+    const long total = (long)(n_nodes + n_edges) * k;
+    hipLaunchKernelGGL(type_attr_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (int)k,
+                       (int)(n_types * k), (const int*)types, (long)n_nodes, (const int*)src, (const int*)dst, (long)n_edges, 1 << n,
+                       g_node_attr, g_edge_attr, g_table);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "type attributes backward: %s", hipGetErrorString(e));
     return CSMPN_OK;
 }
 

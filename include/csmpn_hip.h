@@ -318,6 +318,20 @@ int csmpn_embed_cemlp_backward(const float* metric_host, int n, const csmpn_bloc
                                int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
                                const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* Node / edge attributes of the simplicial task models from per-type features (md17_cssmpnn.py:122-133 embed_simplex_types:
+ * sim_type_embedding(node_types) embedded as scalars, edge attribute = (source, target) attributes side by side):
+ *   node_attr[s][k][0]     = table[types[s]][k]                 [n_nodes, K, D], the other blades 0
+ *   edge_attr[e][k][0]     = table[types[src[e]]][k]            [n_edges, 2 K, D]
+ *   edge_attr[e][K + k][0] = table[types[dst[e]]][k]
+ * table [n_types, K] (nn.Embedding.weight; n_types * K <= 64), types [n_nodes] in [0, n_types), src / dst = edge_index[0] /
+ * edge_index[1] (original edge order), all int32. backward: g_table[t][k] += the blade-0 gradients of every row that read
+ * table[t][k] (accumulated: the caller zeroes g_table; either gradient may be NULL; float atomics on n_types * K values). */
+int csmpn_type_attr_forward(int n, const float* table, int32_t n_types, int32_t k, const int32_t* types, int64_t n_nodes,
+                            const int32_t* src, const int32_t* dst, int64_t n_edges, float* node_attr, float* edge_attr, void* stream);
+int csmpn_type_attr_backward(int n, int32_t n_types, int32_t k, const int32_t* types, int64_t n_nodes, const int32_t* src,
+                             const int32_t* dst, int64_t n_edges, const float* g_node_attr, const float* g_edge_attr, float* g_table,
+                             void* stream);
+
 /* Scalar readout + loss of the convex-hulls model (hulls_cssmpnn.py:93,155-164):
  *   pred_g = mean_{s in graph g} (sum_c weight[c * weight_stride] * x[s][c][0]) + bias,  loss_g = (pred_g - target_g)^2
  * weight points at MVLinear.weight[0] (out_features = 1; weight_stride = n+1 with subspaces, else 1),
