@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     ap.add_argument("--profile-ops", action="store_true", help="torch.profiler over 3 eager steps: the small GPU kernels by Python call site")
+    ap.add_argument("--no-flat-params", action="store_true", help="optimizer over the module's ~1 000 parameter tensors instead of ONE flat buffer (csmpn_hip.graphed.flatten_parameters)")
     ap.add_argument("--op-sites", action="store_true", help="GPU kernels of one eager step by the package line that launched them")
     args = ap.parse_args()
     importlib.import_module(PKG)
@@ -142,7 +143,9 @@ def main():
     model = {"hulls": M.HullsSimplicialMPNN, "md17": M.MD17SimplicialMPNN, "motion": M.MotionSimplicialMPNN}[args.model]().to(dev)
     # the reference trains with torch.optim.Adam (csmpn/configs/hulls.yaml); fused=True is the same update in one
     # multi-tensor kernel (the default foreach path with capturable=True issues ~300 per-tensor div kernels: 1.5 ms)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True,
+    from csmpn_hip.graphed import flatten_parameters
+    opt_params = model.parameters() if args.no_flat_params else [flatten_parameters(model)]
+    opt = torch.optim.Adam(opt_params, lr=1e-3, capturable=True,
                            **({"foreach": True} if args.no_fused_adam else {"fused": True}))
 
     def eager():
@@ -186,7 +189,7 @@ def main():
              "motion": "motion (Cl(3,0), 16 channels, 4 layers)"}[args.model]
     print(json.dumps({"model": label, "graphs_per_batch": args.batch,
                       "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
-                      "fused_grad_accumulation": not args.no_fused_grads, "fused_adam": not args.no_fused_adam, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
+                      "fused_grad_accumulation": not args.no_fused_grads, "fused_adam": not args.no_fused_adam, "flat_parameters": not args.no_flat_params, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
                       "loss": float(gs.loss.detach())}))
 
 
