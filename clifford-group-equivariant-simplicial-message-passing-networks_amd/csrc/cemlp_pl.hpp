@@ -322,14 +322,24 @@ CSMPN_DEV void pl_weighted_gp(float (&out)[PS<ALG>::DL], const float (&z)[PS<ALG
         zE[j] = pl_even(zE[j]);
         ro[j] = pl_partner(rw[j]);
     }
+    // the path weights of class q + 1 are requested in front of the products of class q (every class is its own scheduling
+    // region: left at their use, each pair of LDS reads stalled the wave for its latency - 2 x QP times per product)
+    float wn[2];
+    auto ldw = [&](auto qq, float (&w)[2]) {
+        constexpr int q = decltype(qq)::value;
+        w[0] = wrow[ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q]];
+        w[1] = wrow[ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q]];
+    };
+    ldw(std::integral_constant<int, 0>{}, wn);
     static_for<0, QP>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
         constexpr int ka = P::t.qg[q][0], kc = P::t.qg[q][1], kb = P::t.qg[q][2];
         constexpr int a0 = P::t.cstart[ka], a1 = P::t.cstart[ka + 1];
         constexpr int c0 = P::t.cstart[kc], nc = P::t.cstart[kc + 1] - c0;
         constexpr int b0 = P::t.cstart[kb], b1 = P::t.cstart[kb + 1];
-        const float wA = wrow[ge.s ? P::t.pid[1][0][q] : P::t.pid[0][0][q]];
-        const float wB = wrow[ge.s ? P::t.pid[1][1][q] : P::t.pid[0][1][q]] * (ge.s ? 1.0f : float(P::t.I2));
+        const float wA = wn[0];
+        const float wB = wn[1] * (ge.s ? 1.0f : float(P::t.I2));
+        if constexpr (q + 1 < QP) ldw(std::integral_constant<int, q + 1>{}, wn);
         float tA[nc], tB[nc];
 #pragma unroll
         for (int t = 0; t < nc; ++t) { tA[t] = 0.f; tB[t] = 0.f; }
@@ -351,6 +361,16 @@ CSMPN_DEV void pl_weighted_gp(float (&out)[PS<ALG>::DL], const float (&z)[PS<ALG
     pl_tilde<ALG>(gp, ge);
 #pragma unroll
     for (int j = 0; j < DL; ++j) out[j] += gp[j];
+}
+
+// the four reference path weights of path class Q (LDS): [even lanes' product A, B, odd lanes' A, B]
+template <class ALG, int Q>
+CSMPN_DEV void pl_ld_paths(float (&w)[4], const float* wrow) {
+    using P = PS<ALG>;
+    w[0] = wrow[P::t.pid[0][0][Q]];
+    w[1] = wrow[P::t.pid[0][1][Q]];
+    w[2] = wrow[P::t.pid[1][0][Q]];
+    w[3] = wrow[P::t.pid[1][1][Q]];
 }
 
 // backward of pl_weighted_gp in two passes (each keeps four operand copies live instead of eight).
@@ -382,6 +402,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlSta
         Go[j] = pl_partner(Gw[j]);
     }
     CSMPN_PHASE();
+    float wn[4];
+    pl_ld_paths<ALG, 0>(wn, wrow);
     static_for<0, QP>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
         constexpr int ka = P::t.qg[q][0], kc = P::t.qg[q][1], kb = P::t.qg[q][2];
@@ -389,8 +411,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlSta
         constexpr int c0 = P::t.cstart[kc], nc = P::t.cstart[kc + 1] - c0;
         constexpr int b0 = P::t.cstart[kb], nb = P::t.cstart[kb + 1] - b0;
         // d/dz of the even lanes: w00 Ge (x) Re + w10 Go (x) Ro; of the odd lanes: w11 Go (x) Re + I^2 w01 Ge (x) Ro
-        const float w00 = wrow[P::t.pid[0][0][q]], w01 = wrow[P::t.pid[0][1][q]] * i2;
-        const float w10 = wrow[P::t.pid[1][0][q]], w11 = wrow[P::t.pid[1][1][q]];
+        const float w00 = wn[0], w01 = wn[1] * i2, w10 = wn[2], w11 = wn[3];
+        if constexpr (q + 1 < QP) pl_ld_paths<ALG, q + 1>(wn, wrow);   // next class: in front of this class's products
         const float u1 = ge.s ? w11 : w00, u2 = ge.s ? w01 : w10;
         float S1[na], S2[na], S3[na];
 #pragma unroll
@@ -447,6 +469,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_r(const float (&ggp)[PS<ALG>::DL], const PlSta
         Go[j] = pl_partner(Gw[j]);
     }
     CSMPN_PHASE();
+    float wn[4];
+    pl_ld_paths<ALG, 0>(wn, wrow);
     static_for<0, QP>([&](auto qq) {
         constexpr int q = decltype(qq)::value;
         constexpr int ka = P::t.qg[q][0], kc = P::t.qg[q][1], kb = P::t.qg[q][2];
@@ -454,8 +478,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_r(const float (&ggp)[PS<ALG>::DL], const PlSta
         constexpr int c0 = P::t.cstart[kc], nc = P::t.cstart[kc + 1] - c0;
         constexpr int b0 = P::t.cstart[kb], nb = P::t.cstart[kb + 1] - b0;
         // d/dr of the even lanes: w00 Ge (x) Ze + w11 Go (x) Zo; of the odd lanes: w10 Go (x) Ze + I^2 w01 Ge (x) Zo
-        const float w00 = wrow[P::t.pid[0][0][q]], w01 = wrow[P::t.pid[0][1][q]] * i2;
-        const float w10 = wrow[P::t.pid[1][0][q]], w11 = wrow[P::t.pid[1][1][q]];
+        const float w00 = wn[0], w01 = wn[1] * i2, w10 = wn[2], w11 = wn[3];
+        if constexpr (q + 1 < QP) pl_ld_paths<ALG, q + 1>(wn, wrow);
         const float v1 = ge.s ? w10 : w00, v2 = ge.s ? w01 : w11;
         float V1[nb], V2[nb];
 #pragma unroll
