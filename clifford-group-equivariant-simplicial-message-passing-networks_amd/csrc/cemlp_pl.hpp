@@ -376,10 +376,12 @@ CSMPN_DEV void pl_ld_paths(float (&w)[4], const float* wrow) {
 // backward of pl_weighted_gp in two passes (each keeps four operand copies live instead of eight).
 // Pass Z: gz += d/dz, gwA / gwB += the gradients of the lane's two forward weight sets (the I^2 factor of wB is
 // applied when the sums are written out). Pass R: gr = d/dr.
-template <class ALG>
+// totA / totB: this thread's running sums of the weight gradients of path class 0 (LDS, STRIDE floats between classes):
+// a class's two sums are READ in front of its terms and written behind them - as a read-modify-write at the end each pair
+// stalled the wave for an LDS round trip, 2 x QP times per product backward at one wave per SIMD.
+template <class ALG, int STRIDE>
 CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlState<ALG>& S, const float* wrow,
-                                    const PlGeo<ALG>& ge, float (&gz)[PS<ALG>::DL], float (&gwA)[PS<ALG>::QP],
-                                    float (&gwB)[PS<ALG>::QP]) {
+                                    const PlGeo<ALG>& ge, float (&gz)[PS<ALG>::DL], float* totA, float* totB) {
     using P = PS<ALG>;
     constexpr int DL = P::DL, QP = P::QP;
     const float i2 = float(P::t.I2);
@@ -413,6 +415,7 @@ CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlSta
         // d/dz of the even lanes: w00 Ge (x) Re + w10 Go (x) Ro; of the odd lanes: w11 Go (x) Re + I^2 w01 Ge (x) Ro
         const float w00 = wn[0], w01 = wn[1] * i2, w10 = wn[2], w11 = wn[3];
         if constexpr (q + 1 < QP) pl_ld_paths<ALG, q + 1>(wn, wrow);   // next class: in front of this class's products
+        const float oldA = totA[q * STRIDE], oldB = totB[q * STRIDE];
         const float u1 = ge.s ? w11 : w00, u2 = ge.s ? w01 : w10;
         float S1[na], S2[na], S3[na];
 #pragma unroll
@@ -438,9 +441,8 @@ CSMPN_DEV void pl_weighted_gp_bwd_z(const float (&ggp)[PS<ALG>::DL], const PlSta
             k3 += zo[a0 + t] * S3[t];
         }
         // even lanes: K1 -> w00 (product A), K3 -> w01 (product B); odd lanes: K3 -> w10 (A), K1 -> w11 (B)
-        gwA[q] += ge.s ? k3 : k1;
-        gwB[q] += ge.s ? k1 : k3;
-        asm volatile("" : "+v"(gwA[q]), "+v"(gwB[q]));
+        totA[q * STRIDE] = oldA + (ge.s ? k3 : k1);
+        totB[q * STRIDE] = oldB + (ge.s ? k1 : k3);
         pl_pin<a0, a0 + na>(gzt);
     });
     pl_tilde<ALG>(gzt, ge);
@@ -671,17 +673,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
     pl_wgrad<ALG>(accWL, ggp, z);
     CSMPN_PHASE();
     // ---- geometric product backward
-    {
-        float gwA[P::QP], gwB[P::QP];
-#pragma unroll
-        for (int q = 0; q < P::QP; ++q) { gwA[q] = 0.f; gwB[q] = 0.f; }
-        pl_weighted_gp_bwd_z<ALG>(ggp, S, lds + LY::p_w(K) + c * ALG::P, ge, gz, gwA, gwB);
-#pragma unroll
-        for (int q = 0; q < P::QP; ++q) {
-            pl_sum_add(tot + (SI::wA + q) * kPlThreads, gwA[q]);
-            pl_sum_add(tot + (SI::wB + q) * kPlThreads, gwB[q]);
-        }
-    }
+    pl_weighted_gp_bwd_z<ALG, kPlThreads>(ggp, S, lds + LY::p_w(K) + c * ALG::P, ge, gz, tot + SI::wA * kPlThreads, tot + SI::wB * kPlThreads);
     CSMPN_PHASE();
     float gr[DL];
     pl_weighted_gp_bwd_r<ALG>(ggp, S, lds + LY::p_w(K) + c * ALG::P, ge, gr);

@@ -587,17 +587,7 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     });
     CSMPN_PHASE();
     // ---- geometric product backward
-    {
-        float gwA[P::QP], gwB[P::QP];
-#pragma unroll
-        for (int q = 0; q < P::QP; ++q) { gwA[q] = 0.f; gwB[q] = 0.f; }
-        pl_weighted_gp_bwd_z<ALG>(ggp, S, lds + CF::p_w(K) + c * ALG::P, ge, gz, gwA, gwB);
-#pragma unroll
-        for (int q = 0; q < P::QP; ++q) {
-            plw_sum_add<NT>(tot, SI::wA + q, gwA[q]);
-            plw_sum_add<NT>(tot, SI::wB + q, gwB[q]);
-        }
-    }
+    pl_weighted_gp_bwd_z<ALG, NT>(ggp, S, lds + CF::p_w(K) + c * ALG::P, ge, gz, tot + SI::wA * NT, tot + SI::wB * NT);
     CSMPN_PHASE();
     float gr[DL];
     pl_weighted_gp_bwd_r<ALG>(ggp, S, lds + CF::p_w(K) + c * ALG::P, ge, gr);
