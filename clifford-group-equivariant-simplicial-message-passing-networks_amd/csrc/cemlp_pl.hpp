@@ -640,6 +640,11 @@ template <class ALG, class LY, int K>
 CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const PlState<ALG>& S,
                                  const float (&gout)[PS<ALG>::DL], float (&gy)[PS<ALG>::DL], float* tot,
                                  f4 (&accWR)[PS<ALG>::GC], f4 (&accWL)[PS<ALG>::GC]) {
+    // the 3 + 3 GC per-channel running sums of this thread (LDS): read here, written at the end of the block - as
+    // read-modify-writes where the values are produced each one stalled the wave for an LDS round trip
+    float sums[3 + 3 * PS<ALG>::GC];
+#pragma unroll
+    for (int i = 0; i < 3 + 3 * PS<ALG>::GC; ++i) sums[i] = tot[i * kPlThreads];
     using P = PS<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G;
     const float* ldsn = lds + ge.n;
@@ -650,7 +655,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
 #pragma unroll
     for (int j = 0; j < DL; ++j) dot += gout[j] * S.s[j];
     using SI = PlSumIdx<ALG>;
-    pl_sum_add(tot + SI::la * kPlThreads, dot * S.invMn);   // own half; the partner lane adds its own
+    sums[SI::la] += (dot * S.invMn);   // own half; the partner lane adds its own
     dot += pl_partner(dot);
     const float gMn = pl_chan_sum(-(la * dot) * S.invMn * S.invMn);   // sum over the 8 channels (lanes of this parity)
     const float inl = fast_rcp(S.nl);
@@ -661,7 +666,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
         const float gs = (la * gout[j]) * S.invMn + gqs * (2.0f * ge.template qs<j>()) * S.s[j];
         ggp[j] = gs * kInvSqrt2;
     });
-    pl_sum_add(tot + SI::bL * kPlThreads, ggp[0]);   // (read back from the even lanes only)
+    sums[SI::bL] += (ggp[0]);   // (read back from the even lanes only)
     CSMPN_PHASE();
     // ---- d/dz from linear_left; gWL += GL (x) Z
     float z[DL];
@@ -691,7 +696,7 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
         gden *= S.invden[k] * S.invden[k];
         const float sg = lds[LY::p_sg(K) + c * G + ge.grade(k)];
         const float nu = smooth_abs_sqrt1(qR);
-        pl_sum_add(tot + (SI::an + k) * kPlThreads, gden * (nu - 1.0f) * sg * (1.0f - sg));
+        sums[SI::an + k] += (gden * (nu - 1.0f) * sg * (1.0f - sg));
         const float inu = fast_rcp(nu);
         const float gq = (gden * sg) * (0.5f * qR) * (inu * inu * inu);
         static_for<j0, j1>([&](auto jj) {
@@ -714,8 +719,8 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
         const bool scalar_inv = k == 0 && ge.s == 0;
         if (scalar_inv) u = S.y[0];
         const float gpre = ggate * S.gate[k] * (1.0f - S.gate[k]);
-        pl_sum_add(tot + (SI::sa + k) * kPlThreads, gpre * u);
-        pl_sum_add(tot + (SI::sb + k) * kPlThreads, gpre);
+        sums[SI::sa + k] += (gpre * u);
+        sums[SI::sb + k] += (gpre);
         const float gu = gpre * lds[LY::p_sa(K) + c * G + ge.grade(k)];
         static_for<j0, j1>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -726,7 +731,9 @@ CSMPN_DEV void pl_block_backward(const float* lds, const PlGeo<ALG>& ge, const P
             gy[j] = v;
         });
     });
-    pl_sum_add(tot + SI::b1 * kPlThreads, gy[0]);
+    sums[SI::b1] += (gy[0]);
+#pragma unroll
+    for (int i = 0; i < 3 + 3 * PS<ALG>::GC; ++i) tot[i * kPlThreads] = sums[i];
 }
 
 // ---------------------------------------------------------------------------------

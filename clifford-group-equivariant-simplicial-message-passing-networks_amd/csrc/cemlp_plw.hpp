@@ -545,6 +545,11 @@ template <class ALG, class CF, int K>
 CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG>& ge, int wave, bool cvalid,
                                   const PlState<ALG>& S, const float (&gout)[PS<ALG>::DL], float (&gy)[PS<ALG>::DL],
                                   float* tot, f4 (&accWR)[CF::NG][PS<ALG>::GC], f4 (&accWL)[CF::NG][PS<ALG>::GC]) {
+    // the 3 + 3 GC per-channel running sums of this thread (LDS): read here, written at the end of the block - as
+    // read-modify-writes where the values are produced each one stalled the wave for an LDS round trip
+    float sums[3 + 3 * PS<ALG>::GC];
+#pragma unroll
+    for (int i = 0; i < 3 + 3 * PS<ALG>::GC; ++i) sums[i] = tot[i * (64 * CF::NG)];
     using P = PS<ALG>;
     using SI = PlSumIdx<ALG>;
     constexpr int DL = P::DL, GC = P::GC, G = ALG::G, NG = CF::NG, NT = 64 * NG;
@@ -556,7 +561,7 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < DL; ++j) dot += gout[j] * S.s[j];
-    plw_sum_add<NT>(tot, SI::la, dot * S.invMn);
+    sums[SI::la] += (dot * S.invMn);
     dot += pl_partner(dot);
     const float part = pl_chan_sum(cvalid ? -(la * dot) * S.invMn * S.invMn : 0.f);
     const float gMn = plw_group_sum<CF>(lds, 1, wave, ge.q, part);
@@ -568,7 +573,7 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
         const float gs = (la * gout[j]) * S.invMn + gqs * (2.0f * ge.template qs<j>()) * S.s[j];
         ggp[j] = cvalid ? gs * kInvSqrt2 : 0.f;
     });
-    plw_sum_add<NT>(tot, SI::bL, ggp[0]);
+    sums[SI::bL] += (ggp[0]);
     CSMPN_PHASE();
     // ---- linear_left: d/dz and gWL
     float gz[DL];
@@ -605,7 +610,7 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
         gden *= S.invden[k] * S.invden[k];
         const float sg = lds[CF::p_sg(K) + c * G + ge.grade(k)];
         const float nu = smooth_abs_sqrt1(qR);
-        plw_sum_add<NT>(tot, SI::an + k, gden * (nu - 1.0f) * sg * (1.0f - sg));
+        sums[SI::an + k] += (gden * (nu - 1.0f) * sg * (1.0f - sg));
         const float inu = fast_rcp(nu);
         const float gq = (gden * sg) * (0.5f * qR) * (inu * inu * inu);
         static_for<j0, j1>([&](auto jj) {
@@ -636,8 +641,8 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
         const bool scalar_inv = k == 0 && ge.s == 0;
         if (scalar_inv) u = S.y[0];
         const float gpre = ggate * S.gate[k] * (1.0f - S.gate[k]);
-        plw_sum_add<NT>(tot, SI::sa + k, gpre * u);
-        plw_sum_add<NT>(tot, SI::sb + k, gpre);
+        sums[SI::sa + k] += (gpre * u);
+        sums[SI::sb + k] += (gpre);
         const float gu = gpre * lds[CF::p_sa(K) + c * G + ge.grade(k)];
         static_for<j0, j1>([&](auto jj) {
             constexpr int j = decltype(jj)::value;
@@ -648,7 +653,9 @@ CSMPN_DEV void plw_block_backward(float* lds, const float* tabs, const PlGeo<ALG
             gy[j] = cvalid ? v : 0.f;
         });
     });
-    plw_sum_add<NT>(tot, SI::b1, gy[0]);
+    sums[SI::b1] += (gy[0]);
+#pragma unroll
+    for (int i = 0; i < 3 + 3 * PS<ALG>::GC; ++i) tot[i * (64 * CF::NG)] = sums[i];
 }
 
 // end of a backward launch: the workgroup's MFMA tiles -> its slice of the partial buffer (plain coalesced stores);
