@@ -264,10 +264,12 @@ def make_stages(kind="hulls"):
     """The intermediate tensors of a task model on its loss fixture's parameters and batch (model_<kind>.npz) - the output
     of embed_simplicial_complex (hulls_cssmpnn.py:96-125, md17_cssmpnn.py:85-120) and x behind each EGCL layer
     (hulls_cssmpnn.py:89-94, md17_cssmpnn.py:160-164) - so that the embedding stage and the layer stack are
-    pinned separately from the loss. Round 3: hulls; round 4: md17. Per tensor and per run (float32, float64): its norm and
+    pinned separately from the loss. Round 3: hulls; round 4: md17, motion (motion_cssmpnn.py:90-123), nba (nba_cssmpnn.py:126-157). Per tensor and per run (float32, float64): its norm and
     its dot product with a seeded Gaussian direction; from the float64 run every 8th row whole (as float32)."""
     cls, seed, mk_batch, bseed = {"hulls": (HullsCliffordSharedSimplicialMPNN, 101, hulls_batch, 7),
-                                  "md17": (CliffordSharedSimplicialMPNN_md17, 202, md17_batch, 9)}[kind]
+                                  "md17": (CliffordSharedSimplicialMPNN_md17, 202, md17_batch, 9),
+                                  "motion": (MotionCliffordSharedSimplicialMPNN, 303, motion_batch, 11),
+                                  "nba": (NBACliffordSharedSimplicialMPNN, 404, nba_batch, 13)}[kind]
     ref = np.load(os.path.join(HERE, f"model_{kind}.npz"))
     out = {}
     torch.manual_seed(seed)
