@@ -923,10 +923,24 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                 }
                 plw_block_backward<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, g1, gy0, tot, aWR, aWL);
             }
-            static_for<0, NCH0>([&](auto jc) {
+            // d/dW1 needs EVERY input chunk in EVERY wave (own output group x chunk j): the chunks are gathered ONCE per
+            // workgroup - wave w takes the chunks w, w + NG, .. - and handed round through the exchange buffers (chunk j in
+            // slot j % NG of buffer j / NG; all three are free here), instead of NG redundant gathers of NCH0 chunks, each
+            // one exposed at one wave per SIMD
+            static_assert(NCH0 <= CF::NXB * NG, "chunk slots");
+            float* xb0c = lds + CF::x_off(0);
+            __syncthreads();               // z (buffer 0) and the last gradient exchange (buffer 2) are read no more
+            for (int j = wave; j < NCH0; j += NG) {
                 float x[DL];
-                load_chunk(decltype(jc)::value, x);
-                pl_wgrad<ALG>(aW1[decltype(jc)::value], gy0, x);
+                load_chunk(j, x);
+                plw_put<ALG>(xb0c + (j / NG) * CF::XB, j % NG, ge.lane, x);
+            }
+            __syncthreads();
+            static_for<0, NCH0>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                float x[DL];
+                plw_get<ALG>(x, xb0c + (j / NG) * CF::XB, j % NG, ge.lane);
+                pl_wgrad<ALG>(aW1[j], gy0, x);
             });
             __syncthreads();
             plw_put<ALG>(xb2, wave, ge.lane, gy0);
