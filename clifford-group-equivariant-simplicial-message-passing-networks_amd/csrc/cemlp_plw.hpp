@@ -420,8 +420,22 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
         PlState<ALG> S;
 #pragma unroll
         for (int j = 0; j < DL; ++j) S.y[j] = 0.f;
+        // the first 2 NG input chunks are gathered once per workgroup (wave w: chunks w, w + NG) and handed round through
+        // the two exchange buffers, free at the top of a tile; further chunks (the node program's attributes) per wave
+        constexpr int NSH = NCH0 < 2 * NG ? NCH0 : 2 * NG;
+        float* xbc = lds + CF::x_off(0);
+        for (int j = wave; j < NSH; j += NG) {
+            float x[DL];
+            load_chunk(j, x);
+            plw_put<ALG>(xbc + (j / NG) * CF::XB, j % NG, ge.lane, x);
+        }
+        __syncthreads();
         plw_mix_loop<ALG>(S.y, tabs + CF::t_W1(0) + (wave * NCH0 * 16 + ge.n) * 24, CF::PAIR, NCH0,
-                          [&](int j, float (&x)[DL]) { load_chunk(j, x); });
+                          [&](int j, float (&x)[DL]) {
+                              if (j < NSH) plw_get<ALG>(x, xbc + (j / NG) * CF::XB, j % NG, ge.lane);
+                              else load_chunk(j, x);
+                          });
+        __syncthreads();                  // the chunk slots of buffer 0 are read no more (the tail puts z there)
         float out[DL];
         plw_block_tail<ALG, CF, 0>(lds, tabs, ge, wave, cvalid, S, out);
         // CSMPN_FLAG_SAVE_STATE (EGCL stages, fused two-block embedding): the blocks' s, y, R -> regions 2 + K, 4 + K, 6 + K of the saved buffer, lane
