@@ -14,12 +14,14 @@ on synthetic input already resident in HBM.
 Workload (BASELINE.json configs[1]): S1 = Cl(3,0), 8 channels,
 10 000 nodes, 100 000 directed adjacencies per GPU, aggr=mean, seeded generator.
 With N > 1 GPUs the adjacency list of an N x 100k-edge complex over the same 10k nodes is
-sharded (100k edges per rank, weak scaling). Default partitioning A (BASELINE.json's wording): contiguous
-edge shards with an all-reduce of the per-node aggregate (forward) and of [d/dh | edge-model
-gradients] (backward). `--partition B` (csmpn_hip/sharded.py): every rank owns a node slice (cut by
-in-degree) and all edges into it - all-gather of the updated node slices forward, reduce-scatter of
-d/dh backward, all-reduce of the parameter gradients. `--scaling strong --workload S2` shards ONE 1M-edge complex (north_star's
-multi-GPU configuration) instead and also reports the compute-only rate and the bus bandwidth.
+sharded (100k edges per rank, weak scaling). `python bench.py --gpus N` without a launcher starts the N ranks itself
+(child processes of torch.distributed.run, before this process touches a GPU). Default partitioning B
+(csmpn_hip/sharded.py; SURVEY.md §8(e)'s recommendation): every rank owns a node slice (cut by in-degree) and all edges
+into it - all-gather of the updated node slices forward, reduce-scatter of d/dh backward, all-reduce of the parameter
+gradients. `--partition A` (BASELINE.json's wording): contiguous edge shards with an all-reduce of the per-node aggregate
+(forward) and of [d/dh | edge-model gradients] (backward); its replicated node stage bounds the strong-scaling speed-up
+at 4.0x on 8 GPUs. `--scaling strong --workload S2` shards ONE 1M-edge complex (north_star's multi-GPU
+configuration) instead; both report the compute-only rate and the bus bandwidth (partition B).
 """
 import argparse
 import importlib
@@ -190,6 +192,34 @@ def cpu_baseline(metric, C, state, cpu_inputs, budget_s=20.0, aggr="mean"):
                       f"{torch.__version__} CPU threads={cores} of {os.cpu_count()} host cores"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <the same arguments>` as a child process on a free loopback port. Every line the ranks print is relayed as it comes;
+    rank 0's JSON line is held back and printed LAST on stdout. Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,25 +234,44 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = the workload's edges PER rank; strong = ONE complex sharded over the ranks")
-    ap.add_argument("--partition", default="A", choices=["A", "B"],
-                    help="N > 1: A = edge shards + all-reduce of the per-node aggregate (BASELINE.json's wording, the "
-                         "default); B = destination-partitioned (all-gather / reduce-scatter; never yet measured on RCCL)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "A", "B"],
+                    help="N > 1: A = edge shards + all-reduce of the per-node aggregate (BASELINE.json's wording; its "
+                         "replicated node stage bounds the strong-scaling speed-up at 4.0x on 8 GPUs, DESIGN.md §5); "
+                         "B = destination-partitioned (all-gather / reduce-scatter, half the bytes, no replicated "
+                         "stage). auto = B")
     ap.add_argument("--deterministic", action="store_true",
                     help="atomic-free aggregation (CSMPN_FLAG_DETERMINISTIC): edge rows to a table + fixed-order segmented sums")
+    ap.add_argument("--rehearse-backend", default=None, metavar="MODULE:ATTR",
+                    help="launch-path rehearsal where there is no GPU (tests only): CPU tensors, gloo, the sharded step "
+                         "computed by the injected backend object instead of the HIP C-ABI. The line is marked "
+                         "'rehearsal' and its value is NOT a measurement")
+    ap.add_argument("--rehearse-size", default="64,512", metavar="NODES,EDGES",
+                    help="with --rehearse-backend: nodes, edges per rank instead of the workload's")
     args = ap.parse_args()
 
+    if args.partition == "auto":
+        args.partition = "B"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Plain `python bench.py --gpus N`: start the N ranks as CHILD processes (torch.distributed.run) before anything
+        # in this process has touched the GPU (importing torch does not), relay their output and exit with their code.
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}: the line would report a wrong n_gpus")
     import torch.distributed as dist
     # one rank per GPU; the modulo only matters for rehearsing the N > 1 path on a box with fewer
     # GPUs than ranks (--dist-backend gloo: RCCL refuses two ranks on one device)
-    device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
-    torch.cuda.set_device(device)
+    rehearsal = args.rehearse_backend is not None
+    if rehearsal:
+        device = torch.device("cpu")
+        args.dist_backend = "gloo" if args.dist_backend == "nccl" else args.dist_backend
+        args.no_graph = True
+    else:
+        device = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(device)
+    sync = (lambda: None) if rehearsal else torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
@@ -236,6 +285,11 @@ def main():
         ops.set_deterministic(True)
 
     metric, C, N, E_per = WORKLOADS[args.workload]
+    backend = ops.HipBackend
+    if rehearsal:
+        mod, attr = args.rehearse_backend.split(":")
+        backend = getattr(importlib.import_module(mod), attr)
+        N, E_per = (int(v) for v in args.rehearse_size.split(","))
     D = 1 << len(metric)
     E_total = E_per * world if args.scaling == "weak" else E_per
     part_b = world > 1 and args.partition == "B"
@@ -256,15 +310,15 @@ def main():
 
     segments = None
     if part_b:
-        sl = sharded.DstPartitionedEGCL(layer)
+        sl = sharded.DstPartitionedEGCL(layer, backend=backend)
         plan = sl.plan(ei, N)
         ea = ea[plan.edge_ids].contiguous()
 
         def step():
             y = sl(h, plan, ea, na)
             return torch.autograd.grad(y, [h] + params, gout)
-    elif world > 1 or args.segments:
-        sl = sharded.ShardedEGCL(layer)
+    elif world > 1 or args.segments or rehearsal:
+        sl = sharded.ShardedEGCL(layer, backend=backend)
         plan = sl.plan(ei, N)
 
         def step():
@@ -278,32 +332,32 @@ def main():
     # warm-up (builds the CSR once, sets kernel attributes)
     for _ in range(max(args.warmup, 1)):
         step()
-    torch.cuda.synchronize()
+    sync()
 
-    use_graph = (world == 1) and not args.no_graph and not args.segments
+    use_graph = (world == 1) and not args.no_graph and not args.segments and not rehearsal
     graph = None
     if (world > 1 or args.segments) and not args.no_graph:
         # compute stages as two HIP graphs, the two collectives eager between them
         try:
             segments = (sharded.GraphedDstStep if part_b else sharded.GraphedShardedStep)(sl, plan, h, ea, na, gout)
             segments.run()
-            torch.cuda.synchronize()
+            sync()
         except Exception as exc:
             print(f"[bench] graph segments unavailable ({type(exc).__name__}: {exc}); launching eagerly", file=sys.stderr)
             segments = None
-            torch.cuda.synchronize()
+            sync()
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 graph_out = step()
             graph.replay()
-            torch.cuda.synchronize()
+            sync()
         except Exception as exc:   # capture is an optimisation of the launch path only
             print(f"[bench] HIP-graph capture unavailable ({type(exc).__name__}: {exc}); launching eagerly",
                   file=sys.stderr)
             graph = None
-            torch.cuda.synchronize()
+            sync()
     run = graph.replay if graph is not None else (segments.run if segments is not None else step)
     for _ in range(2):
         run()
@@ -317,11 +371,11 @@ def main():
         edges_per_rank = cnt.tolist()
         assert sum(edges_per_rank) == E_total, (edges_per_rank, E_total)   # every adjacency on exactly one rank
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -335,11 +389,11 @@ def main():
     compute_only = None
     if part_b and segments is not None:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             segments.run(compute_only=True)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         tc = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)
@@ -351,7 +405,18 @@ def main():
                         "bus_GBps_per_rank": round(segments.bytes_per_step / coll_s / 1e9, 2)}
 
     result = None
-    if rank == 0:
+    if rank == 0 and rehearsal:
+        result = {"metric": "launch-path rehearsal (CPU tensors, injected backend): NOT a measurement",
+                  "value": round(value, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling,
+                  "vs_baseline": None, "dtype": "f32", "data": "rehearsal",
+                  "config": {"workload": f"rehearsal of {args.workload}: {N} nodes, {E_per} edges per rank",
+                             "partition": None if world == 1 else args.partition, "edges_per_rank": edges_per_rank,
+                             "pad_ratio": round(plan.pad_ratio, 4) if part_b else None,
+                             "local_share": round(plan.local_share, 4) if part_b else None,
+                             "backend": args.rehearse_backend, "dist_backend": args.dist_backend},
+                  "roofline": None, "cpu_baseline": None}
+    elif rank == 0:
         # ---- per-stage kernel time (HIP events on the launch stream, weights pre-packed)
         be = ops.HipBackend
         spec = layer.spec()
@@ -377,13 +442,13 @@ def main():
         stage_ms, stage_kernel = {}, {}
         for name, fn in stages.items():
             fn()
-            torch.cuda.synchronize()
+            sync()
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
             for a, b in evs:
                 a.record()
                 fn()
                 b.record()
-            torch.cuda.synchronize()
+            sync()
             stage_ms[name] = statistics.median(a.elapsed_time(b) for a, b in evs)
             stage_kernel[name] = native.lib().csmpn_last_kernel().decode()   # what the entry point dispatched
         ab = algorithmic_bytes(C, D)
@@ -428,6 +493,9 @@ def main():
                                     "all-reduce(param grads) bwd" if part_b else
                                     "A: edge list sharded, all-reduce(agg) fwd + all-reduce([dh|edge grads]) bwd"),
                        "edges_per_rank": edges_per_rank,
+                       "partition": None if world == 1 else args.partition,
+                       "pad_ratio": round(plan.pad_ratio, 4) if part_b else None,
+                       "local_share": round(plan.local_share, 4) if part_b else None,
                        "compute_only": compute_only},
             "roofline": roofline,
         }
@@ -435,7 +503,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not rehearsal:
             result["cpu_baseline"] = cpu_baseline(metric, C, state, cpu_inputs, args.cpu_budget, aggr=aggr)
         print(json.dumps(result))
 
