@@ -86,6 +86,12 @@ class SimplexEmbedding(nn.Module):
                 emb_feat = self.algebra.embed_grade(t0, g0).contiguous()      # [S, K, D]: no vertex-order blow-up
                 if "verts_i32" not in plan:
                     plan["verts_i32"] = [v.to(torch.int32).contiguous() for v in plan["verts"]]
+                    # range check once per batch (the C-ABI would repeat it on every forward, with a host round trip)
+                    S = int(emb_feat.shape[0])
+                    for v in plan["verts"]:
+                        if v.numel() and not (0 <= int(v.min()) and int(v.max()) < S):
+                            raise IndexError(f"simplex vertex rows outside [0, {S}) (x_ind / x_ind_ptr of the batch)")
+                    plan["verts_rows_checked"] = S
         # (Tried in round 4 and dropped: the modules of the dimensions as parallel branches on side streams - forward and,
         # through autograd's stream rule, backward. Two long independent chains overlap in a replayed HIP graph (1 618 ->
         # 851 us in a probe), these short forks do not pay for their joins: md17 step 3.13 -> 3.27 ms, hulls 4.80 -> 4.91.)
@@ -102,7 +108,8 @@ class SimplexEmbedding(nn.Module):
         if emb_feat is not None and d >= 1:
             from csmpn_hip import ops
             mod = self.cl_feature_embedding[d]
-            return ops.embed_cemlp_apply(emb_feat, plan["verts_i32"][d], nperm, mod.binding(), mod.flat_params())
+            return ops.embed_cemlp_apply(emb_feat, plan["verts_i32"][d], nperm, mod.binding(), mod.flat_params(),
+                                         validated=plan.get("verts_rows_checked") == int(emb_feat.shape[0]))
         if fused:
             from csmpn_hip import ops
             x = ops.simplex_rows(n, [(t, g) for t, g in vertex_blocks], pv)   # one gather + embed kernel
@@ -136,11 +143,15 @@ def embedded_type_attributes(algebra: CliffordAlgebra, table: nn.Embedding, batc
     """embed_simplex_types of the models with a learned type embedding (md17_cssmpnn.py:122-133): node_attr [S, K, D] and
     edge_attr [E, 2 K, D]. On the device one launch each way (csmpn_type_attr_*); the index tables are cached on the batch."""
     ei = batch.edge_index
-    if table.weight.is_cuda and table.weight.dtype == torch.float32:
+    # the fused kernels sum the table gradient in 64 LDS bins (n_types * K values): larger tables take the composed path
+    if table.weight.is_cuda and table.weight.dtype == torch.float32 and table.weight.numel() <= 64:
         from csmpn_hip import ops
         plan = batch.plan(max_dim)
         if "types_i32" not in plan:
-            plan["types_i32"] = batch.node_types.to(torch.int32).contiguous()
+            nt = batch.node_types
+            if nt.numel() and not (0 <= int(nt.min()) and int(nt.max()) < table.num_embeddings):   # once per batch
+                raise IndexError(f"node_types outside [0, {table.num_embeddings}) (nn.Embedding would raise too)")
+            plan["types_i32"] = nt.to(torch.int32).contiguous()
             plan["ei_i32"] = (ei[0].to(torch.int32).contiguous(), ei[1].to(torch.int32).contiguous())
         return ops.type_attr_apply(table.weight, plan["types_i32"], plan["ei_i32"][0], plan["ei_i32"][1], algebra.dim)
     return type_attributes(algebra, type_embedding(table, batch.node_types), ei)

@@ -26,7 +26,13 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
     the module with ONE fused launch and zeroes all gradients with one fill: the task models carry 700-1 100 small parameter
     tensors (226 per EGCL layer), which torch's multi-tensor Adam walks in 5-7 launches of ~9 us each, its zero_grad in 3.
     Names, shapes and state_dict() of the module are unchanged (the parameters stay the module's own objects; only their
-    storage moves). Elementwise optimizers only (Adam, SGD, ...): per-tensor statistics would see one tensor."""
+    storage moves). Elementwise optimizers only (Adam, SGD, ...): per-tensor statistics would see one tensor.
+
+    ZEROING THE GRADIENTS: the aliasing lives in the .grad attributes. `optimizer.zero_grad()` / `module.zero_grad()` with
+    PyTorch's default `set_to_none=True` REPLACE them - the optimizer then sees `flat.grad is None` and skips the only
+    parameter it has while the module's gradients accumulate elsewhere: training stops silently. Use
+    `zero_flat_grad(flat)` (one fill) or `zero_grad(set_to_none=False)`; `flat_gradients_intact(flat)` tells whether the
+    views still alias (GraphedTrainStep checks it before it captures)."""
     params = [p for p in module.parameters() if p.requires_grad]
     if not params:
         raise ValueError("module has no trainable parameters")
@@ -49,7 +55,23 @@ def flatten_parameters(module: torch.nn.Module) -> torch.nn.Parameter:
             p.grad = gflat[o:o + n].view(p.shape)
     flat_param = torch.nn.Parameter(flat)
     flat_param.grad = gflat
+    flat_param._csmpn_flat = (gflat, params, offs)
     return flat_param
+
+
+def zero_flat_grad(flat_param: torch.nn.Parameter) -> None:
+    """Zero every gradient of a flatten_parameters() module with one fill, keeping the views (the safe zero_grad)."""
+    flat_param._csmpn_flat[0].zero_()
+
+
+def flat_gradients_intact(flat_param: torch.nn.Parameter) -> bool:
+    """True while flat.grad is the flat gradient buffer and every parameter's .grad is still its view of it (False after a
+    zero_grad(set_to_none=True) on the optimizer or the module)."""
+    gflat, params, offs = flat_param._csmpn_flat
+    if flat_param.grad is not gflat:
+        return False
+    esz = gflat.element_size()
+    return all(p.grad is not None and p.grad.data_ptr() == gflat.data_ptr() + o * esz for p, o in zip(params, offs))
 
 
 class GraphedTrainStep:
@@ -75,6 +97,10 @@ class GraphedTrainStep:
         # tensors); parameters and optimizer state are restored afterwards, so the first replayed step is
         # step 1 of the trajectory
         params = [p for g in optimizer.param_groups for p in g["params"]]
+        for p in params:
+            if hasattr(p, "_csmpn_flat") and not flat_gradients_intact(p):
+                raise RuntimeError("flatten_parameters(): the gradient views no longer alias the flat buffer (a zero_grad with "
+                                   "set_to_none=True ran?) - the optimizer would skip every update; use zero_flat_grad()")
         for p in params:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)

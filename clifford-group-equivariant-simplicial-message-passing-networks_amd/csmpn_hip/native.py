@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CSMPN_LIB") or os.path.join(_HERE, "libcsmpn_hip.so")
 
+ABI_VERSION = 2     # include/csmpn_hip.h: csmpn_abi_version()
 MAX_BLOCKS = 4
 FLAG_WEIGHTS_PACKED = 1
 FLAG_NO_VALIDATE = 2
@@ -92,6 +93,10 @@ def _load():
             f"make -C {os.path.join(os.path.dirname(_HERE), 'csrc')})."
         )
     lib = C.CDLL(LIB_PATH)
+    lib.csmpn_abi_version.restype = C.c_int
+    if lib.csmpn_abi_version() != ABI_VERSION:
+        raise NativeLibraryMissing(f"{LIB_PATH} has ABI version {lib.csmpn_abi_version()}, this package binds version "
+                                   f"{ABI_VERSION}: rebuild it (make -C {os.path.join(os.path.dirname(_HERE), 'csrc')})")
     vp, i32, i64, sz, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_uint32
     fp = C.POINTER(C.c_float)
     bp, bg = C.POINTER(BlockParams), C.POINTER(BlockGrads)
@@ -107,7 +112,7 @@ def _load():
     sig("csmpn_geometric_product_backward", C.c_int, [fp, C.c_int, vp, vp, vp, vp, vp, i64, vp])
     sig("csmpn_cemlp_workspace_bytes", sz, [C.c_int, bp, C.c_int])
     sig("csmpn_cemlp_saved_floats_per_row", sz, [C.c_int, bp, C.c_int])
-    sig("csmpn_cemlp_saved_floats", sz, [C.c_int, bp, C.c_int, i64])
+    sig("csmpn_cemlp_saved_floats", sz, [C.c_int, bp, C.c_int, i64, u32])
     sig("csmpn_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, vp, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_mvlinear_forward", C.c_int, [C.c_int, vp, vp, vp, i64, i32, i32, i32, vp, vp])
@@ -133,8 +138,8 @@ def _load():
     sig("csmpn_egcl_node_backward", C.c_int,
         [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, sz, u32, vp])
     sig("csmpn_simplex_rows", C.c_int, [C.c_int, C.POINTER(VertexBlock), C.c_int, vp, i64, i32, i64, vp, vp])
-    sig("csmpn_embed_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
-    sig("csmpn_embed_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_embed_cemlp_forward", C.c_int, [fp, C.c_int, bp, C.c_int, vp, i64, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
+    sig("csmpn_embed_cemlp_backward", C.c_int, [fp, C.c_int, bp, bg, C.c_int, vp, i64, i32, vp, i32, i32, i64, vp, vp, vp, sz, u32, vp])
     sig("csmpn_type_attr_forward", C.c_int, [C.c_int, vp, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp])
     sig("csmpn_type_attr_backward", C.c_int, [C.c_int, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp])
     sig("csmpn_readout_mse_forward", C.c_int, [C.c_int, vp, vp, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp])

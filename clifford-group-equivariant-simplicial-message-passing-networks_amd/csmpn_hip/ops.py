@@ -130,14 +130,17 @@ class CemlpBinding:
         if self._ws_bytes is None:
             self._ws_bytes = int(native.lib().csmpn_cemlp_workspace_bytes(self.n, self.params, self.nblk))
 
-    def new_saved(self, rows: int, device) -> Optional[torch.Tensor]:
-        """Buffer for the inputs of blocks 1.. (written by forward, read by backward)."""
+    def new_saved(self, rows: int, device, save_state: bool = False) -> Optional[torch.Tensor]:
+        """Buffer for the inputs of blocks 1.. (written by forward, read by backward). save_state: the forward / backward pair
+        will be called with CSMPN_FLAG_SAVE_STATE - the buffer also holds the state regions (3-4x the block inputs on the
+        D = 32 and 32-channel shapes)."""
         if self._saved_per_row is None:
             self._saved_per_row = int(native.lib().csmpn_cemlp_saved_floats_per_row(self.n, self.params, self.nblk))
         if self._saved_per_row == 0 or rows == 0:
             return None
         # the size of THIS launch: regions a launch of `rows` rows never touches are left out (csmpn_cemlp_saved_floats)
-        return torch.empty(int(native.lib().csmpn_cemlp_saved_floats(self.n, self.params, self.nblk, rows)),
+        return torch.empty(int(native.lib().csmpn_cemlp_saved_floats(self.n, self.params, self.nblk, rows,
+                                                                     native.FLAG_SAVE_STATE if save_state else 0)),
                            dtype=torch.float32, device=device)
 
     def workspace(self, device) -> torch.Tensor:
@@ -256,18 +259,22 @@ class _EmbedCemlpFn(torch.autograd.Function):
 
     @staticmethod
     @_on_device_of(1)
-    def forward(ctx, vertex_feat, verts, n_orders, binding: CemlpBinding, *params):
+    def forward(ctx, vertex_feat, verts, n_orders, validated, binding: CemlpBinding, *params):
         _require_device(vertex_feat, "embedding vertex features")
         binding.bind(params)
         rows = int(verts.shape[0])
         out = torch.empty(rows // n_orders, binding.out_features, binding.D, dtype=torch.float32, device=vertex_feat.device)
         ws = binding.workspace(vertex_feat.device)
-        need_grad = any(ctx.needs_input_grad[4:])
-        saved = binding.new_saved(rows, vertex_feat.device) if need_grad else None
+        need_grad = any(ctx.needs_input_grad[5:])
+        saved = binding.new_saved(rows, vertex_feat.device, _SAVE_STATE and binding.nblk > 1) if need_grad else None
         # the layer's own saved buffer, sized for exactly these rows: CSMPN_FLAG_SAVE_STATE (two-block modules: y, R, s)
         st_flag = native.FLAG_SAVE_STATE if (_SAVE_STATE and saved is not None and binding.nblk > 1) else 0
+        # validated: the caller has range-checked verts against vertex_feat's rows once (the batch plan); otherwise the entry
+        # point does, with one host round trip (not capturable)
+        st_flag |= native.FLAG_NO_VALIDATE if validated else 0
         check(native.lib().csmpn_embed_cemlp_forward(
-            binding.metric_arr, binding.n, binding.params, binding.nblk, vertex_feat.data_ptr(), int(vertex_feat.shape[1]),
+            binding.metric_arr, binding.n, binding.params, binding.nblk, vertex_feat.data_ptr(), int(vertex_feat.shape[0]),
+            int(vertex_feat.shape[1]),
             verts.data_ptr(), int(verts.shape[1]), int(n_orders), rows, out.data_ptr(), _ptr(saved), ws.data_ptr(), ws.numel(),
             st_flag, _stream(vertex_feat.device)))
         ctx.st_flag = st_flag
@@ -291,9 +298,11 @@ class _EmbedCemlpFn(torch.autograd.Function):
         _flat, views = binding.new_grads(params, vertex_feat.device, fused_into=fused)
         check(native.lib().csmpn_embed_cemlp_backward(
             binding.metric_arr, binding.n, binding.params, binding.grads, binding.nblk, vertex_feat.data_ptr(),
-            int(vertex_feat.shape[1]), verts.data_ptr(), int(verts.shape[1]), ctx.n_orders, int(verts.shape[0]),
-            gout.data_ptr(), _ptr(ctx.saved), ctx.ws.data_ptr(), ctx.ws.numel(), ctx.st_flag, _stream(vertex_feat.device)))
-        return (None, None, None, None, *views)
+            int(vertex_feat.shape[0]), int(vertex_feat.shape[1]), verts.data_ptr(), int(verts.shape[1]), ctx.n_orders,
+            int(verts.shape[0]), gout.data_ptr(), _ptr(ctx.saved), ctx.ws.data_ptr(), ctx.ws.numel(),
+            ctx.st_flag | native.FLAG_NO_VALIDATE,     # the forward has checked (or the caller vouched for) this table
+            _stream(vertex_feat.device)))
+        return (None, None, None, None, None, *views)
 
 
 def embed_cemlp_supported(binding: CemlpBinding, verts_per_row: int, channels_per_vertex: int) -> bool:
@@ -302,8 +311,10 @@ def embed_cemlp_supported(binding: CemlpBinding, verts_per_row: int, channels_pe
             and verts_per_row * channels_per_vertex == binding.in_features <= 8)
 
 
-def embed_cemlp_apply(vertex_feat, verts_i32, n_orders, binding: CemlpBinding, params):
-    return _EmbedCemlpFn.apply(vertex_feat, verts_i32, n_orders, binding, *params)
+def embed_cemlp_apply(vertex_feat, verts_i32, n_orders, binding: CemlpBinding, params, validated=False):
+    """validated=True: every entry of verts_i32 is known to lie in [0, vertex_feat.shape[0]) (checked once per batch by the
+    caller); False: the C-ABI checks on every forward (one synchronous round trip)."""
+    return _EmbedCemlpFn.apply(vertex_feat, verts_i32, n_orders, bool(validated), binding, *params)
 
 
 # --------------------------------------------------------------------------------- CSR
@@ -478,7 +489,7 @@ class HipBackend:
         # slice of a larger one: sharded split forward); the backward finds the flag on the tensor
         st_flag = 0
         if saved is None and save:
-            saved = e.new_saved(csr.n_edges, h.device)
+            saved = e.new_saved(csr.n_edges, h.device, _SAVE_STATE)
             if _SAVE_STATE and saved is not None:
                 st_flag = native.FLAG_SAVE_STATE
                 saved.csmpn_save_state = True
@@ -515,7 +526,7 @@ class HipBackend:
         N, D = h.shape[0], nd.D
         out = torch.empty(N, nd.out_features, D, dtype=torch.float32, device=h.device)
         ws = nd.workspace(h.device)
-        saved = nd.new_saved(N, h.device) if save else None
+        saved = nd.new_saved(N, h.device, _SAVE_STATE) if save else None
         st_flag = 0
         if _SAVE_STATE and saved is not None:
             st_flag = native.FLAG_SAVE_STATE

@@ -1,6 +1,8 @@
 // C-ABI of the library (declared in include/csmpn_hip.h): host-side table
 // construction, launch planning, weight packing, CSR build and dispatch to the
 // per-algebra kernel instantiations.
+#include <atomic>
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -907,6 +909,9 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
                 io.rl_partials = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - pb) & ~(size_t)15));
                 io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // see csmpn_cemlp_saved_floats_per_row
             }
+            // the state regions of the 32-channel forward exist only while its pair backward is enabled (state_channels():
+            // under CSMPN_NO_CM_BWD=1 the saved buffer holds block inputs + the general kernels' hand-over slots, nothing else)
+            if (channels == 32 && !cm_bwd_enabled()) io.save_state = 0;
             bool handled = false;
             const bool debug_cm = sw().debug;
             if (debug_cm) fprintf(stderr, "[csmpn] cm mode=%d bwd=%d channels=%d i0=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, i0, grid, io.rows);
@@ -918,6 +923,15 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
                 return CSMPN_OK;
             }
         }
+    }
+    if ((id == ALG_N5 || id == ALG_N5M) && bwd && mode != MODE_PLAIN && io.rows >= 4096 && !getenv("CSMPN_QUIET")) {
+        // a D = 32 EGCL stage outside the parity-lane widths: served, but by the general row-tile kernels whose backward
+        // spills (4.9-5.8 KB of scratch per lane: DESIGN.md §4.6) - say so once instead of being silently slow
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "[csmpn] note: Cl(5,0) / Cl(4,1) layer with %d channels runs on the general row-tile kernels (slow path: "
+                            "their backward spills registers). The parity-lane kernels serve two-block EGCL layers of 8, 16, 24, 28 "
+                            "or 32 channels. (CSMPN_QUIET=1 silences this note.)\n", plan.C.b[0].O);
     }
     if (io.row_store && !plan.det_general)
         return fail(CSMPN_ERR_UNSUPPORTED,
@@ -1130,9 +1144,11 @@ extern "C" {
 const char* csmpn_last_error(void) { return g_csmpn_err; }
 const char* csmpn_last_kernel(void) { return g_last_kernel; }
 
-/* diagnostic (-DCSMPN_STAMPS builds): device buffer of 25 uint64 per-phase cycle sums + wave count */
+#ifdef CSMPN_STAMPS
+/* diagnostic library only (`make stamps`, never shipped): device buffer of 25 uint64 per-phase cycle sums + wave count */
 void csmpn_debug_set_stamps(void* device_u64x25) { g_stamps = static_cast<unsigned long long*>(device_u64x25); }
-int csmpn_abi_version(void) { return 1; }
+#endif
+int csmpn_abi_version(void) { return 2; }   // 2 (round 5): csmpn_embed_cemlp_* take n_vertex_rows, csmpn_cemlp_saved_floats takes flags
 const char* csmpn_build_target(void) { return "gfx950"; }
 
 int csmpn_metric_supported(const float* metric_host, int n) { return alg_id(metric_host, n) != ALG_NONE ? 1 : 0; }
@@ -1227,7 +1243,7 @@ static size_t base_channels(int n, const csmpn_block_params* blocks, int n_block
     return ch;
 }
 
-size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows) {
+size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows, uint32_t flags) {
     if (rows <= 0 || !blocks || n_blocks < 1 || n_blocks > CSMPN_MAX_BLOCKS || n < 1 || n > 8) return 0;
     size_t base = base_channels(n, blocks, n_blocks);
     // the general kernels' hand-over slots (one per saved input: the per-row figure doubles for them) are used by the phased
@@ -1236,7 +1252,8 @@ size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_b
         general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows)
         base /= 2;
     const size_t state_rows = (size_t)((rows + 15) & ~(int64_t)15);
-    return ((base * (size_t)rows) << n) + ((state_channels(n, blocks, n_blocks) * state_rows) << n);
+    const size_t state = (flags & CSMPN_FLAG_SAVE_STATE) ? state_channels(n, blocks, n_blocks) : 0;
+    return ((base * (size_t)rows) << n) + ((state * state_rows) << n);
 }
 
 // upper bound per row (the state regions hold up to 15 padding rows more: csmpn_cemlp_saved_floats is exact)
@@ -1312,33 +1329,67 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // standalone CEMLP: no row table, atomic-free parameter sums only
-    io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
+    // CSMPN_FLAG_SAVE_STATE is ignored here, as csmpn_cemlp_forward ignores it (include/csmpn_hip.h): the standalone forward
+    // writes no state regions, so a backward that honoured the flag would read rows nobody wrote
     return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
 }
 
 // Fused simplex embedding (include/csmpn_hip.h): MODE_PLAIN of the wide parity-lane kernels with the embed descriptor
-static int embed_io(const AlgId id, const csmpn_block_params* blocks, const float* vertex_feat, int32_t kpv, const int32_t* verts,
-                    int32_t nv, int32_t n_orders, int64_t n_rows, RowIO& io) {
+__global__ void index_range_kernel(const int* __restrict__ idx, long n, int hi, int* __restrict__ flag) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (idx[i] < 0 || idx[i] >= hi)) atomicOr(flag, 1);
+}
+__device__ int g_range_flag;            // written by index_range_kernel, read back under g_range_mutex
+static std::mutex g_range_mutex;
+
+// every entry of idx[0, n) in [0, hi)? One host round trip (callers that have validated their tables pass
+// CSMPN_FLAG_NO_VALIDATE; the kernels clamp in any case)
+static int check_index_range(const int32_t* idx, int64_t n, int64_t hi, hipStream_t st, const char* what) {
+    if (n <= 0) return CSMPN_OK;
+    std::lock_guard<std::mutex> lock(g_range_mutex);
+    int* flag = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&flag), HIP_SYMBOL(g_range_flag));
+    if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return fail(CSMPN_ERR_HIP, "%s validation: %s", what, hipGetErrorString(e));
+    hipLaunchKernelGGL(index_range_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, (long)n,
+                       (int)(hi > 0x7fffffff ? 0x7fffffff : hi), flag);
+    int host_flag = 0;
+    e = hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return fail(CSMPN_ERR_HIP, "%s validation: %s", what, hipGetErrorString(e));
+    if (host_flag) return fail(CSMPN_ERR_INVALID, "%s has entries outside [0, %lld)", what, (long long)hi);
+    return CSMPN_OK;
+}
+
+static int embed_io(const AlgId id, const csmpn_block_params* blocks, const float* vertex_feat, int64_t n_vertex_rows, int32_t kpv,
+                    const int32_t* verts, int32_t nv, int32_t n_orders, int64_t n_rows, uint32_t flags, hipStream_t st, RowIO& io) {
     if (id != ALG_N5 && id != ALG_N5M) return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: Cl(5,0) / Cl(4,1) only");
     if (n_orders != 1 && n_orders != 2 && n_orders != 6) return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: 1, 2 or 6 vertex orders");
     if (!vertex_feat || !verts || kpv < 1 || nv < 1 || nv * kpv != blocks[0].in_features || nv * kpv > 8)
         return fail(CSMPN_ERR_UNSUPPORTED, "fused embedding: verts_per_row * channels_per_vertex must equal in_features (<= 8)");
     if (n_rows % n_orders) return fail(CSMPN_ERR_INVALID, "fused embedding: n_rows %ld is not a multiple of n_orders %d", (long)n_rows, n_orders);
+    if (n_vertex_rows < 1 || n_vertex_rows > 0x7fffffff)
+        return fail(CSMPN_ERR_INVALID, "fused embedding: n_vertex_rows %lld not in [1, 2^31)", (long long)n_vertex_rows);
+    if (!(flags & CSMPN_FLAG_NO_VALIDATE)) {
+        const int rc = check_index_range(verts, n_rows * nv, n_vertex_rows, st, "fused embedding: verts");
+        if (rc) return rc;
+    }
     memset(&io, 0, sizeof(io));
     io.rows = n_rows; io.nseg = 1;
     io.seg[0].a = vertex_feat; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
-    io.emb_verts = verts; io.emb_nperm = n_orders; io.emb_nv = nv; io.emb_k = kpv;
+    io.emb_verts = verts; io.emb_nperm = n_orders; io.emb_nv = nv; io.emb_k = kpv; io.emb_nrows = (int)n_vertex_rows;
     return CSMPN_OK;
 }
 
 int csmpn_embed_cemlp_forward(const float* metric, int n, const csmpn_block_params* blocks, int n_blocks, const float* vertex_feat,
-                              int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row, int32_t n_orders,
+                              int64_t n_vertex_rows, int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row, int32_t n_orders,
                               int64_t n_rows, float* out, float* save_inputs, void* workspace, size_t workspace_bytes,
                               uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     RowIO io;
-    int rc = embed_io(id, blocks, vertex_feat, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, io);
+    int rc = embed_io(id, blocks, vertex_feat, n_vertex_rows, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, flags,
+                      (hipStream_t)stream, io);
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, nullptr, n_blocks, workspace, workspace_bytes, false, 0, false, n_rows, plan))) return rc;
@@ -1351,13 +1402,14 @@ int csmpn_embed_cemlp_forward(const float* metric, int n, const csmpn_block_para
 }
 
 int csmpn_embed_cemlp_backward(const float* metric, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
-                               int n_blocks, const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts,
-                               int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
+                               int n_blocks, const float* vertex_feat, int64_t n_vertex_rows, int32_t channels_per_vertex,
+                               const int32_t* verts, int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
                                const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream) {
     const AlgId id = alg_id(metric, n);
     if (id == ALG_NONE) return fail(CSMPN_ERR_UNSUPPORTED, "metric not supported by the HIP path");
     RowIO io;
-    int rc = embed_io(id, blocks, vertex_feat, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, io);
+    int rc = embed_io(id, blocks, vertex_feat, n_vertex_rows, channels_per_vertex, verts, verts_per_row, n_orders, n_rows, flags,
+                      (hipStream_t)stream, io);
     if (rc) return rc;
     Plan plan;
     if ((rc = make_plan(id, n, blocks, grads, n_blocks, workspace, workspace_bytes, true, 0, saved_inputs != nullptr, n_rows, plan))) return rc;

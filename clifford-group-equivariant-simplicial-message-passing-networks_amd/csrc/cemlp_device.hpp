@@ -131,7 +131,7 @@ struct RowIO {
     // row seg[0].a[emb_verts[r * emb_nv + v]] ([S, emb_k, D]); the emb_nperm consecutive output rows of a simplex are summed
     // and stored as row r / emb_nperm of y; the backward reads d/d(out) there. emb_nperm = 0: off.
     const int* emb_verts;
-    int emb_nperm, emb_nv, emb_k, pad4_;
+    int emb_nperm, emb_nv, emb_k, emb_nrows;   // emb_nrows = S: vertex ids are clamped into [0, S) (memory safety; the entry point range-checks)
 };
 
 // Storage variants of the row-tile buffers (compile time, so that the LDS variants use

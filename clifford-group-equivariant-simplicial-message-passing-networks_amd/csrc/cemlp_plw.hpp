@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? (CF::fwd_total * 4 
                 (void)seg;
                 if (emb_np) {   // channel ch = vertex ch / emb_k of this row's vertex order, its feature channel ch % emb_k
                     const int v = (on ? ch : 0) / io.emb_k, kk = (on ? ch : 0) % io.emb_k;
-                    const long vr = io.emb_verts[lrow * io.emb_nv + v];
+                    const long vr = min(max(io.emb_verts[lrow * io.emb_nv + v], 0), io.emb_nrows - 1);
                     pl_load<ALG>(x, io.seg[0].a + ((size_t)vr * io.emb_k + kk) * D, ge.s, on ? 1.0f : 0.0f);
                 } else {
                     pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);
@@ -906,7 +906,7 @@ __global__ void __launch_bounds__(64 * CF::NG, CF::NG >= 3 ? CF::WG_PER_CU_BWD :
                     (void)seg;
                     if (io.emb_nperm) {   // fused embedding: see the forward
                         const int v = (on ? ch : 0) / io.emb_k, kk = (on ? ch : 0) % io.emb_k;
-                        const long vr = io.emb_verts[lrow * io.emb_nv + v];
+                        const long vr = min(max(io.emb_verts[lrow * io.emb_nv + v], 0), io.emb_nrows - 1);
                         pl_load<ALG>(x, io.seg[0].a + ((size_t)vr * io.emb_k + kk) * D, ge.s, on ? 1.0f : 0.0f);
                     } else {
                         pl_load<ALG>(x, io.seg[0].a + (size_t)lrow * (NA * D) + co, ge.s, on ? 1.0f : 0.0f);

@@ -115,7 +115,7 @@ __global__ void readout_bwd_kernel(const float* w, int wstride, int C, int D, co
 
 // one thread per (row, k): row < n_nodes -> node_attr[row][k][:], else edge e = row - n_nodes -> edge_attr[e][k][:] and
 // edge_attr[e][K + k][:]; blade 0 = the table entry, the other blades 0
-__global__ void type_attr_fwd_kernel(const float* table, int K, const int* types, long n_nodes, const int* src, const int* dst,
+__global__ void type_attr_fwd_kernel(const float* table, int T, int K, const int* types, long n_nodes, const int* src, const int* dst,
                                      long n_edges, int D, float* node_attr, float* edge_attr) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long row = t / K;
@@ -125,12 +125,15 @@ __global__ void type_attr_fwd_kernel(const float* table, int K, const int* types
         p[0] = v;
         for (int d = 1; d < D; ++d) p[d] = 0.f;
     };
+    // type ids clamped into [0, T): a bad id reads a wrong table row, never out of bounds (callers validate node_types once
+    // per batch - the reference's nn.Embedding would raise)
+    auto ty = [&](long r) { return min(max(types[r], 0), T - 1); };
     if (row < n_nodes) {
-        put(node_attr + (row * K + k) * D, table[types[row] * K + k]);
+        put(node_attr + (row * K + k) * D, table[ty(row) * K + k]);
     } else {
         const long e = row - n_nodes;
-        put(edge_attr + (e * 2 * K + k) * D, table[types[src[e]] * K + k]);
-        put(edge_attr + (e * 2 * K + K + k) * D, table[types[dst[e]] * K + k]);
+        put(edge_attr + (e * 2 * K + k) * D, table[ty(src[e]) * K + k]);
+        put(edge_attr + (e * 2 * K + K + k) * D, table[ty(dst[e]) * K + k]);
     }
 }
 // g_table[t][k] += sum of the blade-0 gradients of every attribute row that read table[t][k]
@@ -143,12 +146,14 @@ __global__ void __launch_bounds__(256) type_attr_bwd_kernel(int K, int TK, const
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long row = t / K;
     const int k = (int)(t % K);
+    const int T = TK / K;
+    auto ty = [&](long r) { return min(max(types[r], 0), T - 1); };   // as the forward: clamped into the bins
     if (row < n_nodes) {
-        if (g_node) atomicAdd(&bins[types[row] * K + k], g_node[(row * K + k) * D]);
+        if (g_node) atomicAdd(&bins[ty(row) * K + k], g_node[(row * K + k) * D]);
     } else if (row < n_nodes + n_edges && g_edge) {
         const long e = row - n_nodes;
-        atomicAdd(&bins[types[src[e]] * K + k], g_edge[(e * 2 * K + k) * D]);
-        atomicAdd(&bins[types[dst[e]] * K + k], g_edge[(e * 2 * K + K + k) * D]);
+        atomicAdd(&bins[ty(src[e]) * K + k], g_edge[(e * 2 * K + k) * D]);
+        atomicAdd(&bins[ty(dst[e]) * K + k], g_edge[(e * 2 * K + K + k) * D]);
     }
     __syncthreads();
     if (threadIdx.x < TK && bins[threadIdx.x] != 0.f) atomicAdd(g_table + threadIdx.x, bins[threadIdx.x]);
@@ -234,7 +239,7 @@ int csmpn_type_attr_forward(int n, const float* table, int32_t n_types, int32_t 
     if (!table || !types || (n_nodes && !node_attr) || (n_edges && (!src || !dst || !edge_attr)))
         return csmpn_fail(CSMPN_ERR_INVALID, "type attributes: null pointer");
     const long total = (long)(n_nodes + n_edges) * k;
-    hipLaunchKernelGGL(type_attr_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)k,
+    hipLaunchKernelGGL(type_attr_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, table, (int)n_types, (int)k,
                        (const int*)types, (long)n_nodes, (const int*)src, (const int*)dst, (long)n_edges, 1 << n, node_attr, edge_attr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "type attributes forward: %s", hipGetErrorString(e));

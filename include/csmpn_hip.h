@@ -48,7 +48,7 @@ extern "C" {
 #define CSMPN_ERR_HIP 3
 
 /* flags of the compute entry points */
-#define CSMPN_FLAG_NO_VALIDATE 2u    /* csmpn_csr_build: skip the (synchronous) range check of edge_index */
+#define CSMPN_FLAG_NO_VALIDATE 2u    /* csmpn_csr_build, csmpn_embed_cemlp_*: skip the (synchronous) range check of the index table */
 #define CSMPN_FLAG_WEIGHTS_PACKED 1u /* forward entry points: the workspace already holds this
                                        CEMLP's packed weights (left there by an earlier forward with
                                        the same parameters): skip the pack kernel. Accepted and
@@ -155,9 +155,12 @@ size_t csmpn_cemlp_saved_floats_per_row(int n, const csmpn_block_params* blocks,
  * regions a launch of that size never touches - the general kernels' hand-over region exists only for launches that can
  * take the block-by-block backward (rows >= its threshold, default 4096; CSMPN_PHASED_MIN_ROWS): a 940-row node stage of a
  * multi-block CEMLP of the small algebras pays half. A buffer of this size is valid for forward and backward of that
- * launch. The CSMPN_FLAG_SAVE_STATE regions are counted with the rows rounded up to a multiple of 16 (whole row tiles):
- * for those shapes the result may exceed rows * per-row figure by up to 15 rows of state. */
-size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows);
+ * launch. flags (ABI version 2): with CSMPN_FLAG_SAVE_STATE the state regions of that flag are included - pass the flag
+ * here iff the forward / backward pair will be called with it (they are 3-4x the block inputs on the D = 32 and 32-channel
+ * shapes: H28 248 instead of 56 channels x 32 floats per edge); without it the buffer holds block inputs + hand-over only.
+ * The regions are counted with the rows rounded up to a multiple of 16 (whole row tiles): for those shapes the result may
+ * exceed rows * per-row figure by up to 15 rows of state. */
+size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_blocks, int64_t rows, uint32_t flags);
 
 /* y[rows, O_last, D] = CEMLP(x[rows, I_0, D]). */
 int csmpn_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
@@ -306,16 +309,18 @@ int csmpn_simplex_rows(int n, const csmpn_vertex_block* blocks, int n_blocks, co
  *   out [n_simplices, O, D]: out[s] = sum over its n_orders rows of CEMLP(concat_v vertex_feat[verts[r][v]]).
  * Neither the [n_rows, I, D] input rows nor the [n_rows, O, D] per-order outputs exist in memory; the sum is taken in
  * registers in row order (no atomics). n_orders in {1, 2, 6}. save_inputs / saved_inputs as for csmpn_cemlp_* (rows = n_rows).
- * PRECONDITION: every entry of verts lies in [0, n_feature_rows) - the kernels gather vertex_feat rows with them unchecked
- * (an out-of-range entry is an out-of-bounds device read); callers validate once per batch (csmpn/data/complexes.py plan()).
+ * n_vertex_rows = n_feature_rows (ABI version 2). Every entry of verts must lie in [0, n_vertex_rows): both entry points
+ * range-check the table (one synchronous host round trip on `stream`, as csmpn_csr_build) and return CSMPN_ERR_INVALID
+ * otherwise; a caller that has validated its table once per batch passes CSMPN_FLAG_NO_VALIDATE (required inside a stream
+ * capture). The kernels clamp the ids into [0, n_vertex_rows) in any case: a bad id reads a wrong row, never out of bounds.
  * backward: d/d(parameters) only (the features are data); g_out [n_simplices, O, D]. */
 int csmpn_embed_cemlp_forward(const float* metric_host, int n, const csmpn_block_params* blocks, int n_blocks,
-                              const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts, int32_t verts_per_row,
-                              int32_t n_orders, int64_t n_rows, float* out, float* save_inputs, void* workspace,
-                              size_t workspace_bytes, uint32_t flags, void* stream);
+                              const float* vertex_feat, int64_t n_vertex_rows, int32_t channels_per_vertex, const int32_t* verts,
+                              int32_t verts_per_row, int32_t n_orders, int64_t n_rows, float* out, float* save_inputs,
+                              void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 int csmpn_embed_cemlp_backward(const float* metric_host, int n, const csmpn_block_params* blocks, const csmpn_block_grads* grads,
-                               int n_blocks, const float* vertex_feat, int32_t channels_per_vertex, const int32_t* verts,
-                               int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
+                               int n_blocks, const float* vertex_feat, int64_t n_vertex_rows, int32_t channels_per_vertex,
+                               const int32_t* verts, int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
                                const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
 /* Node / edge attributes of the simplicial task models from per-type features (md17_cssmpnn.py:122-133 embed_simplex_types:

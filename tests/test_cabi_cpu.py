@@ -21,8 +21,14 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = native.lib()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.csmpn_abi_version() == 1
+    assert lib.csmpn_abi_version() == native.ABI_VERSION == 2
     assert lib.csmpn_build_target() == b"gfx950"
+    # ... and NOTHING else: the dynamic symbol table (defined function symbols) is exactly the header's list - no csmpn::
+    # launchers, no template instances, no diagnostic hooks (csrc/exports.map)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1].split("@")[0] for l in nm.splitlines() if len(l.split()) >= 3 and l.split()[-2] in "TtWw"}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 @pytest.mark.parametrize("name", ALGS)
@@ -129,3 +135,22 @@ def test_modules_copy_and_pickle_after_binding(pkg):
     buf.seek(0)
     back = torch.load(buf, weights_only=False)
     assert sorted(back.state_dict()) == sorted(layer.state_dict())
+
+
+def test_flat_parameters_guard_against_set_to_none(pkg):
+    """flatten_parameters keeps its aliasing in the .grad attributes: zero_grad(set_to_none=True) - PyTorch's default -
+    breaks it silently (round-4 advice). flat_gradients_intact() sees it, zero_flat_grad() is the safe fill."""
+    from csmpn_hip.graphed import flat_gradients_intact, flatten_parameters, zero_flat_grad
+    m = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    flat = flatten_parameters(m)
+    opt = torch.optim.SGD([flat], lr=0.1)
+    m(torch.randn(4, 3)).sum().backward()
+    assert flat_gradients_intact(flat) and float(flat.grad.abs().sum()) > 0
+    before = flat.detach().clone()
+    opt.step()
+    assert not torch.equal(before, flat.detach())          # every module parameter moved through the ONE flat update
+    assert torch.equal(m[0].weight.detach().reshape(-1), flat.detach()[:15])
+    zero_flat_grad(flat)
+    assert flat_gradients_intact(flat) and float(m[1].bias.grad.abs().sum()) == 0.0
+    opt.zero_grad()                                          # set_to_none=True: the aliasing is gone
+    assert not flat_gradients_intact(flat)

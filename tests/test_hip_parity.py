@@ -455,6 +455,28 @@ def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path, C):
         assert err < 2e-5, (i, err)
 
 
+def test_channel_mfma_forward_without_its_backward(pkg, tmp_path):
+    """CSMPN_NO_CM_BWD=1 (the documented A/B switch) on the 32-channel width: the channel-MFMA FORWARD still runs, its
+    pair backward does not, and the saved buffer is then sized WITHOUT state regions - the forward must not write any
+    (round-4 advice: it stored y / R / s ~6 KB per row past the end of the allocation). Same gradients as the default
+    path; the log shows the forward family and no channel-MFMA backward."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _CM_BWD_SCRIPT.replace("C, N, E = (1.0, 1.0, 1.0), 16,", "C, N, E = (1.0, 1.0, 1.0), 32,")
+    outs = {}
+    for tag, extra in (("nobwd", {"CSMPN_NO_CM_BWD": "1", "CSMPN_DEBUG": "1"}), ("cm", {"CSMPN_DEBUG": "1"})):
+        f = str(tmp_path / f"g_{tag}.pt")
+        r = subprocess.run([sys.executable, "-c", script, root, f], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "cm mode=1 bwd=0" in r.stderr and "cm mode=2 bwd=0" in r.stderr, r.stderr[-2000:]
+        assert ("cm mode=1 bwd=1" in r.stderr) == (tag == "cm"), r.stderr[-2000:]
+        outs[tag] = torch.load(f)
+    for i, (a, b) in enumerate(zip(outs["nobwd"], outs["cm"])):
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+        assert err < 2e-5, (i, err)
+
+
 @pytest.mark.parametrize("metric,C,N,E,aggr,family", [
     ((1.0, 1.0, 1.0), 8, 700, 30001, "mean", "cemlp_cl_bwd_kernel"),          # S1's kernels: s per block
     ((1.0, 1.0, 1.0), 32, 500, 9001, "sum", "cemlp_cmp_kernel"),              # md17's width: y, R, s per block
