@@ -55,6 +55,8 @@ EXPORTS = (
     "csmpn_type_attr_backward",
     "csmpn_readout_mse_forward",
     "csmpn_readout_mse_backward",
+    "csmpn_readout_traj_forward",
+    "csmpn_readout_traj_backward",
     "csmpn_last_error",
     "csmpn_last_kernel",
     "csmpn_abi_version",
@@ -144,6 +146,9 @@ def _load():
     sig("csmpn_type_attr_backward", C.c_int, [C.c_int, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp, vp])
     sig("csmpn_readout_mse_forward", C.c_int, [C.c_int, vp, vp, i32, vp, i64, i32, vp, i64, vp, vp, vp, vp, vp])
     sig("csmpn_readout_mse_backward", C.c_int, [C.c_int, vp, i32, i64, i32, vp, i64, vp, vp, vp])
+    sig("csmpn_readout_traj_forward", C.c_int, [C.c_int, vp, i32, vp, i64, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp])
+    sig("csmpn_readout_traj_backward", C.c_int,
+        [C.c_int, vp, i32, i64, vp, vp, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp])
     sig("csmpn_last_error", C.c_char_p, [])
     sig("csmpn_last_kernel", C.c_char_p, [])
     sig("csmpn_abi_version", C.c_int, [])

@@ -5,6 +5,10 @@
 //   csmpn_readout_mse_forward / _backward
 //                               scalar readout + loss of the hulls model: MVLinear -> blade 0 -> mean over
 //                               the simplices of a graph -> squared error (hulls_cssmpnn.py:93,155-164)
+//   csmpn_readout_traj_forward / _backward
+//                               vector readout + loss of the trajectory models: MVLinear -> vector blades (+ loc) -> distance
+//                               to the target -> per-graph MSE / ADE / FDE and per-vertex MSE (md17_cssmpnn.py:165-176,
+//                               motion_cssmpnn.py:150-168, nba_cssmpnn.py:176-191)
 //   csmpn_type_attr_forward / _backward
 //                               node / edge attributes of the task models from a learned (or one-hot) table of simplex-type
 //                               features (md17_cssmpnn.py:122-133, hulls_cssmpnn.py:127-140): one launch each way instead
@@ -159,6 +163,161 @@ __global__ void __launch_bounds__(256) type_attr_bwd_kernel(int K, int TK, const
     if (threadIdx.x < TK && bins[threadIdx.x] != 0.f) atomicAdd(g_table + threadIdx.x, bins[threadIdx.x]);
 }
 
+// ---- trajectory readout + loss (md17 / motion / NBA heads: md17_cssmpnn.py:165-176, motion_cssmpnn.py:150-168,
+// nba_cssmpnn.py:176-191): final MVLinear restricted to the vector blades, + loc, distance to the target, per-graph sums.
+constexpr int kTrajMaxOC = 4096;   // out_channels * channels staged in LDS
+constexpr int kTrajItems = 1024;   // (vertex, out channel) items of a graph processed per pass
+
+// one workgroup per graph; item = (vertex v of the graph, out channel o): p[a] = sum_c W[o][c][grade 1] x[row(v)][c][1 + a]
+// (+ loc[v][o][a]); d = p - target[trow(v)][o][:]; fixed-order sums. per_graph[b] = (sum |d|^2 / (cnt O), sum |d| / (cnt O),
+// sum_v |d[v][O-1]| / cnt) over the cnt scored vertices (trow >= 0); per_vertex[v] = sum_{o,a} d^2 / (O n) (0 if not scored).
+__global__ void __launch_bounds__(256) readout_traj_fwd_kernel(const float* x, int C, int D, int n, const int* vrows, const float* w,
+                                                               int O, int wstride, const float* loc, const float* target,
+                                                               const int* trow, const int* vptr, float* pred, float* per_graph,
+                                                               float* per_vertex) {
+    __shared__ float W1[kTrajMaxOC];
+    __shared__ float sq_item[kTrajItems];
+    __shared__ float red[3][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < O * C; i += 256) W1[i] = w[(long)i * wstride + 1];   // grade-1 weight of (o, c)
+    __syncthreads();
+    const int lo = vptr[b], hi = vptr[b + 1];
+    const int vper = kTrajItems / O > 0 ? kTrajItems / O : 1;   // vertices per pass (O <= kTrajItems is checked on the host)
+    float s_sq = 0.f, s_ade = 0.f, s_fde = 0.f;
+    int cnt = 0;
+    for (int v0 = lo; v0 < hi; v0 += vper) {
+        const int nv = min(vper, hi - v0);
+        for (int it = tid; it < nv * O; it += 256) {
+            const int v = v0 + it / O, o = it % O;
+            const long row = vrows ? vrows[v] : v;
+            const int tr = trow ? trow[v] : v;
+            float p[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            const float* xr = x + row * (long)C * D + 1;
+            for (int c = 0; c < C; ++c) {
+                const float wv = W1[o * C + c];
+                for (int a = 0; a < n; ++a) p[a] = fmaf(wv, xr[(long)c * D + a], p[a]);
+            }
+            float sq = 0.f;
+            for (int a = 0; a < n; ++a) {
+                const long e = ((long)v * O + o) * n + a;
+                if (loc) p[a] += loc[e];
+                pred[e] = p[a];
+                if (tr >= 0) {
+                    const float d = p[a] - target[((long)tr * O + o) * n + a];
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            sq_item[it] = sq;
+            if (tr >= 0) {
+                const float nr = sqrtf(sq);
+                s_sq += sq; s_ade += nr;
+                if (o == O - 1) s_fde += nr;
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < nv; j += 256) {     // per-vertex sum over the out channels, in order
+            float a = 0.f;
+            for (int o = 0; o < O; ++o) a += sq_item[j * O + o];
+            const int tr = trow ? trow[v0 + j] : v0 + j;
+            per_vertex[v0 + j] = tr >= 0 ? a / float(O * n) : 0.f;
+            cnt += tr >= 0 ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    red[0][tid] = s_sq; red[1][tid] = s_ade; red[2][tid] = s_fde;
+    __shared__ int cred[256];
+    cred[tid] = cnt;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) {
+            red[0][tid] += red[0][tid + k]; red[1][tid] += red[1][tid + k]; red[2][tid] += red[2][tid + k];
+            cred[tid] += cred[tid + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float cn = float(cred[0] > 1 ? cred[0] : 1);
+        per_graph[b * 3 + 0] = red[0][0] / (cn * O);
+        per_graph[b * 3 + 1] = red[1][0] / (cn * O);
+        per_graph[b * 3 + 2] = red[2][0] / cn;
+    }
+}
+
+// gpred[v][o][a] = d[a] * (g_graph[b][0] 2 / (cnt O) + g_graph[b][1] / (|d| cnt O) + [o == O-1] g_graph[b][2] / (|d| cnt)
+//                          + g_vertex[v] 2 / (O n)),  d = pred - target; 0 for vertices that are not scored. One thread per (v, o).
+__global__ void readout_traj_gpred_kernel(int V, int O, int n, const float* pred, const float* target, const int* trow,
+                                          const int* graph_of_vertex, const int* vptr, const float* g_graph, const float* g_vertex,
+                                          float* gpred) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)V * O) return;
+    const int v = (int)(t / O), o = (int)(t % O);
+    const int tr = trow ? trow[v] : v;
+    float d[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, sq = 0.f;
+    if (tr >= 0)
+        for (int a = 0; a < n; ++a) {
+            d[a] = pred[t * n + a] - target[((long)tr * O + o) * n + a];
+            sq = fmaf(d[a], d[a], sq);
+        }
+    float coef = 0.f;
+    if (tr >= 0) {
+        const int b = graph_of_vertex[v];
+        int cnt = 0;                                    // scored vertices of the graph (graphs are small: a short loop)
+        for (int u = vptr[b]; u < vptr[b + 1]; ++u) cnt += (trow ? trow[u] : u) >= 0 ? 1 : 0;
+        const float cn = float(cnt > 1 ? cnt : 1);
+        const float nr = sqrtf(sq), inv = nr > 0.f ? 1.f / nr : 0.f;
+        if (g_graph) {
+            coef += g_graph[b * 3 + 0] * 2.f / (cn * O) + g_graph[b * 3 + 1] * inv / (cn * O);
+            if (o == O - 1) coef += g_graph[b * 3 + 2] * inv / cn;
+        }
+        if (g_vertex) coef += g_vertex[v] * 2.f / float(O * n);
+    }
+    for (int a = 0; a < n; ++a) gpred[t * n + a] = coef * d[a];
+}
+
+// blocks [0, nbx): gx[s][c][1 + a] = sum_o W[o][c][1] gpred[vertex(s)][o][a], every other element of gx = 0 (one thread
+// per (s, c)); blocks [nbx, nbx + O): g_w[o][c][grade 1] += sum_{v, a} gpred[v][o][a] x[row(v)][c][1 + a] - block = out
+// channel, thread = (c, vertex group), fixed-order sums (no atomics).
+__global__ void __launch_bounds__(256) readout_traj_bwd_kernel(const float* x, int C, int D, int n, long S, const int* vrows,
+                                                               const int* vertex_of_row, int V, const float* w, int O, int wstride,
+                                                               const float* gpred, int nbx, float* gx, float* g_w) {
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < nbx) {
+        const long t = (long)blockIdx.x * 256 + tid;
+        if (t >= S * C) return;
+        const long s = t / C;
+        const int c = (int)(t % C);
+        const int v = vertex_of_row ? vertex_of_row[s] : (int)s;
+        float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (v >= 0)
+            for (int o = 0; o < O; ++o) {
+                const float wv = w[((long)o * C + c) * wstride + 1];
+                for (int a = 0; a < n; ++a) acc[a] = fmaf(wv, gpred[((long)v * O + o) * n + a], acc[a]);
+            }
+        float* g = gx + t * D;
+        for (int d = 0; d < D; ++d) g[d] = (d >= 1 && d <= n) ? acc[d - 1] : 0.f;
+        return;
+    }
+    __shared__ float red[256];
+    const int o = (int)blockIdx.x - nbx;
+    const int groups = 256 / C;                 // C <= 64: at least 4 vertex groups
+    const int c = tid % C, vg = tid / C;
+    float acc = 0.f;
+    if (vg < groups)
+        for (int v = vg; v < V; v += groups) {
+            const long row = vrows ? vrows[v] : v;
+            const float* xr = x + (row * C + c) * (long)D + 1;
+            const float* gp = gpred + ((long)v * O + o) * n;
+            for (int a = 0; a < n; ++a) acc = fmaf(gp[a], xr[a], acc);
+        }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < C) {
+        float sum = 0.f;
+        for (int k = 0; k < groups; ++k) sum += red[k * C + tid];
+        g_w[((long)o * C + tid) * wstride + 1] += sum;
+    }
+}
+
 int grade_start(int n, int g) {
     int s = 0, c = 1;
     for (int i = 0; i < g; ++i) { s += c; c = c * (n - i) / (i + 1); }
@@ -228,6 +387,52 @@ int csmpn_readout_mse_backward(int n, const float* weight, int32_t weight_stride
                        (long)n_rows, gx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "readout backward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_readout_traj_forward(int n, const float* x, int32_t channels, const int32_t* vertex_rows, int64_t n_vertices,
+                               const float* weight, int32_t out_channels, int32_t weight_stride, const float* loc, const float* target,
+                               const int32_t* target_row, const int32_t* vertex_ptr, int64_t n_graphs, float* pred, float* per_graph,
+                               float* per_vertex, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_graphs <= 0 || n_vertices <= 0) return CSMPN_OK;
+    if (!x || !weight || !target || !vertex_ptr || !pred || !per_graph || !per_vertex) return csmpn_fail(CSMPN_ERR_INVALID, "trajectory readout: null pointer");
+    if (channels < 1 || channels > 64 || out_channels < 1 || out_channels > kTrajItems || (long)channels * out_channels > kTrajMaxOC || weight_stride < 2)
+        return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "trajectory readout: channels <= 64, out_channels * channels <= %d, weight [O, C, G >= 2]", kTrajMaxOC);
+    hipLaunchKernelGGL(readout_traj_fwd_kernel, dim3((unsigned)n_graphs), dim3(256), 0, (hipStream_t)stream, x, (int)channels, 1 << n, n,
+                       (const int*)vertex_rows, weight, (int)out_channels, (int)weight_stride, loc, target, (const int*)target_row,
+                       (const int*)vertex_ptr, pred, per_graph, per_vertex);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "trajectory readout forward: %s", hipGetErrorString(e));
+    return CSMPN_OK;
+}
+
+int csmpn_readout_traj_backward(int n, const float* x, int32_t channels, int64_t n_rows, const int32_t* vertex_rows,
+                                const int32_t* vertex_of_row, int64_t n_vertices, const float* weight, int32_t out_channels,
+                                int32_t weight_stride, const float* pred, const float* target, const int32_t* target_row,
+                                const int32_t* graph_of_vertex, const int32_t* vertex_ptr, const float* g_per_graph,
+                                const float* g_per_vertex, float* gpred_scratch, float* gx, float* g_weight, void* stream) {
+    if (n < 1 || n > 5) return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "n = %d generators not supported", n);
+    if (n_rows <= 0) return CSMPN_OK;
+    if (!x || !weight || !pred || !target || !graph_of_vertex || !vertex_ptr || !gpred_scratch || !gx || !g_weight || n_vertices < 0)
+        return csmpn_fail(CSMPN_ERR_INVALID, "trajectory readout: null pointer");
+    if ((vertex_rows == nullptr) != (vertex_of_row == nullptr)) return csmpn_fail(CSMPN_ERR_INVALID, "trajectory readout: vertex_rows and vertex_of_row go together");
+    if (!vertex_rows && n_rows != n_vertices) return csmpn_fail(CSMPN_ERR_INVALID, "trajectory readout: identity vertex rows need n_rows == n_vertices");
+    if (channels < 1 || channels > 64 || out_channels < 1 || out_channels > kTrajItems || (long)channels * out_channels > kTrajMaxOC || weight_stride < 2)
+        return csmpn_fail(CSMPN_ERR_UNSUPPORTED, "trajectory readout: channels <= 64, out_channels * channels <= %d, weight [O, C, G >= 2]", kTrajMaxOC);
+    hipStream_t st = (hipStream_t)stream;
+    const long items = (long)n_vertices * out_channels;
+    if (items > 0)
+        hipLaunchKernelGGL(readout_traj_gpred_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (int)n_vertices,
+                           (int)out_channels, n, pred, target, (const int*)target_row, (const int*)graph_of_vertex,
+                           (const int*)vertex_ptr, g_per_graph, g_per_vertex, gpred_scratch);
+    const long nbx = ((long)n_rows * channels + 255) / 256;
+    if (nbx + out_channels >= (1ll << 31)) return csmpn_fail(CSMPN_ERR_INVALID, "trajectory readout: too many rows");
+    hipLaunchKernelGGL(readout_traj_bwd_kernel, dim3((unsigned)(nbx + out_channels)), dim3(256), 0, st, x, (int)channels, 1 << n, n,
+                       (long)n_rows, (const int*)vertex_rows, (const int*)vertex_of_row, (int)n_vertices, weight, (int)out_channels,
+                       (int)weight_stride, (const float*)gpred_scratch, (int)nbx, gx, g_weight);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return csmpn_fail(CSMPN_ERR_HIP, "trajectory readout backward: %s", hipGetErrorString(e));
     return CSMPN_OK;
 }
 

@@ -323,6 +323,33 @@ int csmpn_embed_cemlp_backward(const float* metric_host, int n, const csmpn_bloc
                                const int32_t* verts, int32_t verts_per_row, int32_t n_orders, int64_t n_rows, const float* g_out,
                                const float* saved_inputs, void* workspace, size_t workspace_bytes, uint32_t flags, void* stream);
 
+/* Vector readout + loss of the trajectory task models (round 5; md17_cssmpnn.py:165-176, motion_cssmpnn.py:150-168,
+ * nba_cssmpnn.py:176-191): the final MVLinear of the head restricted to the vector blades, the residual on the positions, the
+ * distance to the target and the per-graph losses in one launch (fixed-order sums, no atomics).
+ *   x [n_rows, C, D]; vertex_rows [V] int32 = row of x of every vertex (NULL: row v = vertex v, n_rows == V);
+ *   weight [O, C, weight_stride] (layers' MVLinear.weight [O, C, G], subspaces = True: the grade-1 entry is used; the bias
+ *   sits on blade 0 and does not reach the vector blades); loc [V, O, n] or NULL; target [V_t, O, n]; target_row [V] int32 =
+ *   row of target of every vertex, -1 = not scored (NBA: the ball) (NULL: row v); vertex_ptr [B + 1] int32: the vertices of
+ *   graph b are vertex_ptr[b] .. vertex_ptr[b + 1] - 1.
+ *   pred[v][o][a]   = sum_c weight[o][c][1] x[row(v)][c][1 + a] (+ loc[v][o][a])                       [V, O, n]
+ *   d               = pred - target over the cnt_b scored vertices of graph b
+ *   per_graph[b]    = ( sum |d|^2 / (cnt_b O),  sum |d| / (cnt_b O),  sum_v |d[v][O - 1]| / cnt_b )     [B, 3]  (MSE, ADE, FDE)
+ *   per_vertex[v]   = sum_{o, a} d^2 / (O n)  (0 if not scored)                                         [V]
+ * backward: given g_per_graph [B, 3] and / or g_per_vertex [V] (either may be NULL): gx [n_rows, C, D] is WRITTEN (zero
+ * outside the vector blades of the vertex rows; vertex_of_row [n_rows] int32 = vertex of a row or -1, NULL with vertex_rows
+ * NULL), g_weight [O, C, weight_stride] is ACCUMULATED at the grade-1 entries; gpred_scratch [V, O, n] floats of scratch;
+ * graph_of_vertex [V] int32. A zero distance contributes no ADE / FDE gradient (the reference's sqrt backward gives NaN there).
+ * Limits: C <= 64, O <= 1024, O * C <= 4096. */
+int csmpn_readout_traj_forward(int n, const float* x, int32_t channels, const int32_t* vertex_rows, int64_t n_vertices,
+                               const float* weight, int32_t out_channels, int32_t weight_stride, const float* loc, const float* target,
+                               const int32_t* target_row, const int32_t* vertex_ptr, int64_t n_graphs, float* pred, float* per_graph,
+                               float* per_vertex, void* stream);
+int csmpn_readout_traj_backward(int n, const float* x, int32_t channels, int64_t n_rows, const int32_t* vertex_rows,
+                                const int32_t* vertex_of_row, int64_t n_vertices, const float* weight, int32_t out_channels,
+                                int32_t weight_stride, const float* pred, const float* target, const int32_t* target_row,
+                                const int32_t* graph_of_vertex, const int32_t* vertex_ptr, const float* g_per_graph,
+                                const float* g_per_vertex, float* gpred_scratch, float* gx, float* g_weight, void* stream);
+
 /* Node / edge attributes of the simplicial task models from per-type features (md17_cssmpnn.py:122-133 embed_simplex_types:
  * sim_type_embedding(node_types) embedded as scalars, edge attribute = (source, target) attributes side by side):
  *   node_attr[s][k][0]     = table[types[s]][k]                 [n_nodes, K, D], the other blades 0

@@ -93,3 +93,21 @@ def test_twin_rejects_bad_indices():
     ei[1, 0] = 10_000
     with pytest.raises(RuntimeError, match="outside"):
         cpu_twin.egcl_layer([1.0, 1.0, 1.0], p, g[f"{f32}/h"], ei)
+
+
+@pytest.mark.parametrize("tag", ["S1", "M32"])
+def test_twin_float64_vs_reference_fixture_full_size(tag):
+    """The float64 build of the twin - the truth of tests/test_full_size_twin.py, and the only truth of S2 / H28 where the
+    reference's dense formulation does not fit in memory - against the imported reference's own float64 run at FULL size
+    (100 k edges; tests/golden/make_fullsize_golden.py): y and d/dh on the stored node subsample, every parameter gradient."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    T = importlib.import_module("test_full_size_twin")
+    g = np.load(os.path.join(GOLD, f"fullsize_{tag}.npz"))
+    metric, C, aggr, h, ei, ea, na, p, gout, t64, _t32 = T._case(tag)
+    np.testing.assert_allclose(T._input_checksums(h, ei, ea, na, p, gout), g["checksums"], rtol=1e-12, atol=0)
+    st = int(g["node_stride"])
+    assert rel(t64["out"][::st], g["f64/y"]) < 1e-10 and rel(t64["gh"][::st], g["f64/gh"]) < 1e-10
+    for k, v in t64["grads"].items():
+        assert rel(v, g[f"f64/g/{k}"]) < 1e-10, k

@@ -32,8 +32,16 @@ WORKLOADS = {
     "S1": ((1.0, 1.0, 1.0), 8, 10_000, 100_000, "mean", None),
     "S3": ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000, "mean", 0.02),
     "M32": ((1.0, 1.0, 1.0), 32, 10_000, 100_000, "sum", None),
+    # BASELINE config 5 on the RAW generator inputs (no taming of the negative-signature blades: null-cone norms, the
+    # reference's own float32 run is 1e-3 .. 1e-1 off its float64 run on some tensors - reported, bounded by that yardstick)
+    "S3raw": ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 10_000, 100_000, "mean", None),
     "S2": ((1.0, 1.0, 1.0), 16, 100_000, 1_000_000, "mean", None),
+    # the convex-hulls width (hulls_cssmpnn.py:16-28: Cl(5,0), 28 channels) at S1's size: the wide parity-lane kernels
+    "H28": ((1.0, 1.0, 1.0, 1.0, 1.0), 28, 10_000, 100_000, "mean", None),
 }
+# workloads with a fixture of the imported reference's own float64 / float32 run at full size
+# (tests/golden/make_fullsize_golden.py; the reference's dense formulation needs ~35 GB for S3, more for S2 / H28)
+REFERENCE_FIXTURES = ("S1", "M32", "S3", "S3raw")
 _cache = {}
 
 
@@ -91,7 +99,7 @@ def _hip(tag, deterministic):
 
 
 @pytest.mark.parametrize("deterministic", [True, False], ids=["deterministic", "atomic"])
-@pytest.mark.parametrize("tag", list(WORKLOADS))
+@pytest.mark.parametrize("tag", [t for t in WORKLOADS if t != "S3raw"])
 def test_full_size_layer_against_cpu_twin(tag, deterministic):
     *_, t64, t32 = _case(tag)
     y, gh, grads = _hip(tag, deterministic)
@@ -103,3 +111,55 @@ def test_full_size_layer_against_cpu_twin(tag, deterministic):
     yard = max([relmax(t32["out"], t64["out"]), relmax(t32["gh"], t64["gh"])] +
                [relmax(t32["grads"][k], t64["grads"][k]) for k in grads])
     print(f"{tag} {'det' if deterministic else 'atomic'}: worst HIP err {max(errs.values()):.2e}, float32 yardstick {yard:.2e}")
+
+
+def _input_checksums(h, ei, ea, na, p, gout):   # = tests/golden/make_fullsize_golden.py::checksums
+    return np.asarray([h.double().sum().item(), h.double().abs().sum().item(), float(ei.sum().item()),
+                       float((ei[0] * 7 + ei[1]).remainder(1000003).sum().item()), ea.double().sum().item(),
+                       na.double().sum().item(), gout.double().sum().item(),
+                       sum(v.double().abs().sum().item() for v in p.values())], dtype=np.float64)
+
+
+@pytest.mark.parametrize("deterministic", [True, False], ids=["deterministic", "atomic"])
+@pytest.mark.parametrize("tag", REFERENCE_FIXTURES)
+def test_full_size_layer_against_reference_fixture(tag, deterministic, golden_dir):
+    """The same full-size runs against the IMPORTED REFERENCE (round-4 review, item 5): its own EGCL.forward + autograd in
+    float64 (truth) and float32 (yardstick) on these very inputs, recorded in the build container by
+    tests/golden/make_fullsize_golden.py - y and d/dh on a 1-in-16 node subsample, every parameter gradient whole. A defect
+    shared by the HIP kernels and this repository's C++ twin (index width, degree handling, tile bookkeeping at scale)
+    would pass the twin test above and fail here."""
+    path = os.path.join(golden_dir, f"fullsize_{tag}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"no reference fixture for {tag}")
+    g = np.load(path)
+    metric, C, aggr, h, ei, ea, na, p, gout, _, _ = _case(tag)
+    # the inputs are regenerated from the seed, not stored: a drifting generator must not compare different problems
+    np.testing.assert_allclose(_input_checksums(h, ei, ea, na, p, gout), g["checksums"], rtol=1e-12, atol=0)
+    st = int(g["node_stride"])
+    y, gh, grads = _hip(tag, deterministic)
+    # raw Cl(4,1) inputs sit on the null cone: the factor the golden Cl(4,1) cases use (test_hip_parity.py: 10 atomic, 6
+    # deterministic) against the reference's own float32 error; every other workload: 4
+    slack = (6.0 if deterministic else 10.0) if tag == "S3raw" else 4.0
+    errs, report = {}, {}
+    # tensor-level scale = the FULL tensor's maximum (stored), not the subsample's
+    for name, arr in (("y", y), ("gh", gh)):
+        truth, ref32 = g[f"f64/{name}"], g[f"f32/{name}"]
+        scale = float(g[f"f64/{name}_absmax"])
+        yard = float(np.abs(ref32 - truth).max() / scale)
+        err = float(np.abs(arr[::st] - truth).max() / scale)
+        bound = max(1e-5, slack * yard)
+        assert err <= bound, f"{tag} {name}: HIP {err:.2e} vs reference float64, bound {bound:.2e} (reference float32: {yard:.2e})"
+        errs[name] = err
+        report[name] = (err, yard)
+    keys = [k[len("f64/g/"):] for k in g.files if k.startswith("f64/g/")]
+    assert set(keys) == set(grads)
+    for k in keys:
+        errs[k] = check("g." + k, grads[k], g[f"f64/g/{k}"], g[f"f32/g/{k}"], slack=slack)
+        report[k] = (errs[k], relmax(g[f"f32/g/{k}"], g[f"f64/g/{k}"]))
+    print(f"{tag} {'det' if deterministic else 'atomic'} vs reference fixture: worst HIP err {max(errs.values()):.2e}")
+    # per-tensor table (HIP error, the reference's own float32 error; both against the reference's float64 run) for BASELINE.md
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, f"fullsize_errors_{tag}_{'det' if deterministic else 'atomic'}.json"), "w") as f:
+            json.dump({k: {"hip": v[0], "reference_float32": v[1]} for k, v in report.items()}, f, indent=1)
