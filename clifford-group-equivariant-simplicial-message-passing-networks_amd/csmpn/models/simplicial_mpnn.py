@@ -33,6 +33,15 @@ from csmpn.algebra.cliffordalgebra import CliffordAlgebra
 from csmpn.models.cegnn_utils import CEMLP, EGCL, MVLinear
 
 
+def _fused_traj_readout(head, x) -> bool:
+    """The trajectory heads go through csmpn_readout_traj_* on the device (CSMPN_NO_FUSED_READOUT=1: composed ops)."""
+    import os
+    if not x.is_cuda or os.environ.get("CSMPN_NO_FUSED_READOUT", "0") not in ("", "0"):
+        return False
+    from csmpn_hip import ops
+    return ops.readout_traj_supported(head, x)
+
+
 def segment_mean(x: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
     """global_mean_pool: mean of the rows of x per segment id (sum / clamp(count, 1))."""
     out = x.new_zeros((n,) + tuple(x.shape[1:]))
@@ -240,6 +249,26 @@ class MD17SimplicialMPNN(nn.Module):
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
+        return self.readout(batch, x)
+
+    def readout(self, batch, x):
+        """Head + loss behind the message passing (md17_cssmpnn.py:165-176): x [S, hidden, 8] -> (loss, parts)."""
+        B = batch.num_graphs
+        F_ = batch.loc.shape[1]
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        loc_node = batch.loc.index_select(0, vr)
+        head = self.projection[-1]
+        if _fused_traj_readout(head, x):
+            # fused head + loss (csmpn_readout_traj_*): the CEMLP of the head on the vertex rows, then MVLinear -> vector blades
+            # -> + loc -> per-graph MSE / ADE / FDE in one launch each way
+            from csmpn_hip import ops
+            if "traj" not in plan:
+                plan["traj"] = ops.readout_traj_tables(plan["graph_of_vertex"], B)
+            z = self.projection[0](x.index_select(0, vr))
+            per_graph, _pv, _pred = ops.readout_traj(z, head.weight, loc_node, batch.y, plan["traj"], 3)
+            loss = per_graph[:, 0]
+            return loss.mean(), {"loss": loss, "ade_loss": per_graph[:, 1], "fde_loss": per_graph[:, 2]}
         pred = self.projection(x.index_select(0, vr))[..., 1:4]
         loc_pred = loc_node + pred
         tgt = batch.y
@@ -285,6 +314,21 @@ class MotionSimplicialMPNN(nn.Module):
         x = self._embed(batch, [(pos.unsqueeze(1), 1), (batch.vel.unsqueeze(1), 1)])
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
+        return self.readout(batch, x)
+
+    def readout(self, batch, x):
+        """Head + loss behind the message passing (motion_cssmpnn.py:150-163): x [S, hidden, 8] -> (loss, parts)."""
+        B = batch.num_graphs
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        node_pos = batch.pos.index_select(0, vr)
+        head = self.projection[0]
+        if head.out_features == 1 and _fused_traj_readout(head, x):
+            from csmpn_hip import ops      # fused head + loss: vertex rows gathered inside the kernel
+            if "traj" not in plan:
+                plan["traj"] = ops.readout_traj_tables(plan["graph_of_vertex"], B, vertex_rows=vr, n_rows=x.shape[0])
+            _pg, loss, _pred = ops.readout_traj(x, head.weight, node_pos, batch.y, plan["traj"], 3)
+            return loss.mean(), {"loss": loss}
         pred = node_pos + self.projection(x.index_select(0, vr))[..., 0, 1:4]
         loss = ((pred - batch.y.reshape(-1, 3)) ** 2).mean(dim=1)
         return loss.mean(), {"loss": loss}
@@ -342,6 +386,21 @@ class NBASimplicialMPNN(nn.Module):
         x = self.feature_embedding(torch.cat((x, node_attr), dim=1))
         for layer in self.layers:
             x = layer(x, batch.edge_index, edge_attr, node_attr)
+        return self.readout(batch, x)
+
+    def readout(self, batch, x):
+        """Head + loss behind the message passing (nba_cssmpnn.py:176-188): x [S, hidden, 4] -> (loss, parts)."""
+        B = batch.num_graphs
+        F_ = batch.pos.shape[1]
+        plan = batch.plan(self.max_dim)
+        vr = plan["vertex_rows"]
+        if _fused_traj_readout(self.projection, x):
+            from csmpn_hip import ops      # fused head + loss: the last agent of every graph (the ball) is not scored
+            if "traj" not in plan:
+                plan["traj"] = ops.readout_traj_tables(plan["graph_of_vertex"], B, vertex_rows=vr, n_rows=x.shape[0], unscored_last=1)
+            per_graph, _pv, _pred = ops.readout_traj(x, self.projection.weight, None, batch.y, plan["traj"], 2)
+            ade = per_graph[:, 1]
+            return ade.mean(), {"loss": ade, "ade_loss": ade, "fde_loss": per_graph[:, 2]}
         pred = self.projection(x.index_select(0, vr))[..., 1:3]                      # [V, num_out, 2]
         loc_pred = pred.reshape(B, self.agents, self.num_out, -1)[:, :-1].reshape(-1, self.num_out, 2)
         tgt = batch.y

@@ -1088,6 +1088,97 @@ class _ReadoutMseFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None
 
 
+class _ReadoutTrajFn(torch.autograd.Function):
+    """Vector readout + loss of the trajectory models (csmpn_readout_traj_*; md17_cssmpnn.py:165-176,
+    motion_cssmpnn.py:150-168, nba_cssmpnn.py:176-191). Returns (per_graph [B, 3] = MSE / ADE / FDE, per_vertex [V] MSE,
+    pred [V, O, n]); gradients w.r.t. x and the MVLinear weight (its grade-1 entries)."""
+
+    @staticmethod
+    @_on_device_of(1)
+    def forward(ctx, x, weight, loc, target, tables, n):
+        _require_device(x, "readout input")
+        x = x.contiguous()
+        S, Cc, D = x.shape
+        w = weight.contiguous()
+        if w.dim() != 3 or w.shape[1] != Cc or w.shape[2] < 2 or D != (1 << n):
+            raise RuntimeError(f"trajectory readout: weight {tuple(weight.shape)} does not fit input {tuple(x.shape)}")
+        O = int(w.shape[0])
+        vrows, vof, trow, gov, vptr = tables["vrows"], tables["vertex_of_row"], tables["trow"], tables["graph_of_vertex"], tables["vptr"]
+        V, B = int(gov.shape[0]), int(vptr.shape[0]) - 1
+        if vrows is None and S != V:
+            raise RuntimeError("trajectory readout: identity vertex rows need one input row per vertex")
+        tgt = target.contiguous().float().reshape(-1, O, n)
+        lc = None if loc is None else loc.contiguous().float().reshape(V, O, n)
+        pred = torch.empty(V, O, n, dtype=torch.float32, device=x.device)
+        per_graph = torch.empty(B, 3, dtype=torch.float32, device=x.device)
+        per_vertex = torch.empty(V, dtype=torch.float32, device=x.device)
+        check(native.lib().csmpn_readout_traj_forward(n, x.data_ptr(), Cc, _ptr(vrows), V, w.data_ptr(), O, int(w.shape[2]), _ptr(lc),
+                                                      tgt.data_ptr(), _ptr(trow), vptr.data_ptr(), B, pred.data_ptr(),
+                                                      per_graph.data_ptr(), per_vertex.data_ptr(), _stream(x.device)))
+        ctx.save_for_backward(x, w, pred, tgt)
+        ctx.tables, ctx.n = tables, n
+        ctx.mark_non_differentiable(pred)
+        return per_graph, per_vertex, pred
+
+    @staticmethod
+    @_on_device_of(1)
+    def backward(ctx, g_graph, g_vertex, _g_pred):
+        x, w, pred, tgt = ctx.saved_tensors
+        t = ctx.tables
+        S, Cc, D = x.shape
+        V, O, n = pred.shape
+        gg = None if g_graph is None else g_graph.contiguous().float()
+        gv = None if g_vertex is None else g_vertex.contiguous().float()
+        gx = torch.empty_like(x)
+        gw = torch.zeros_like(w)
+        scratch = torch.empty(V, O, n, dtype=torch.float32, device=x.device)
+        check(native.lib().csmpn_readout_traj_backward(
+            ctx.n, x.data_ptr(), Cc, S, _ptr(t["vrows"]), _ptr(t["vertex_of_row"]), V, w.data_ptr(), O, int(w.shape[2]),
+            pred.data_ptr(), tgt.data_ptr(), _ptr(t["trow"]), t["graph_of_vertex"].data_ptr(), t["vptr"].data_ptr(), _ptr(gg),
+            _ptr(gv), scratch.data_ptr(), gx.data_ptr(), gw.data_ptr(), _stream(x.device)))
+        return gx, gw, None, None, None, None
+
+
+def readout_traj_tables(graph_of_vertex, n_graphs, vertex_rows=None, n_rows=None, unscored_last=0):
+    """Index tables of csmpn_readout_traj_* (int32, on the device of graph_of_vertex), built once per batch:
+    vptr [B + 1] (the vertices of a graph are contiguous in the vertex list), graph_of_vertex [V]; with `vertex_rows` (rows of
+    the layer output that are vertices) also its inverse vertex_of_row [n_rows]; unscored_last = k: the last k vertices of
+    every graph are not scored (NBA: the ball) and the target rows number the scored ones consecutively."""
+    gov = graph_of_vertex.to(torch.int64)
+    dev = gov.device
+    V = int(gov.shape[0])
+    if V > 1 and bool((gov[1:] < gov[:-1]).any()):
+        raise RuntimeError("trajectory readout: the vertices of a graph must be contiguous in the vertex list")
+    cnt = torch.bincount(gov, minlength=n_graphs)
+    vptr = torch.zeros(n_graphs + 1, dtype=torch.int64, device=dev)
+    vptr[1:] = torch.cumsum(cnt, 0)
+    trow = None
+    if unscored_last:
+        pos = torch.arange(V, device=dev) - vptr[:-1][gov]                 # position inside the graph
+        scored = pos < (cnt[gov] - unscored_last)
+        first = torch.cumsum(torch.cat([cnt.new_zeros(1), (cnt - unscored_last).clamp(min=0)[:-1]]), 0)
+        trow = torch.where(scored, first[gov] + pos, torch.full_like(pos, -1)).to(torch.int32).contiguous()
+    vrows = vof = None
+    if vertex_rows is not None:
+        vrows = vertex_rows.to(torch.int32).contiguous()
+        vof = torch.full((int(n_rows),), -1, dtype=torch.int32, device=dev)
+        vof[vertex_rows.long()] = torch.arange(V, dtype=torch.int32, device=dev)
+    return {"vrows": vrows, "vertex_of_row": vof, "trow": trow, "graph_of_vertex": gov.to(torch.int32).contiguous(),
+            "vptr": vptr.to(torch.int32).contiguous()}
+
+
+def readout_traj(x, weight, loc, target, tables, n):
+    """(per_graph [B, 3] = (MSE, ADE, FDE), per_vertex [V] MSE, pred [V, O, n]); tables = readout_traj_tables(...)."""
+    return _ReadoutTrajFn.apply(x, weight, loc, target, tables, int(n))
+
+
+def readout_traj_supported(head, x) -> bool:
+    """MVLinear(subspaces=True) heads on device float32 rows within the kernel's limits."""
+    w = getattr(head, "weight", None)
+    return (x.is_cuda and x.dtype == torch.float32 and w is not None and w.dim() == 3 and w.shape[1] <= 64
+            and w.shape[0] <= 1024 and w.shape[0] * w.shape[1] <= 4096)
+
+
 def readout_mse(x, weight, bias, graph_ptr_i32, target, n):
     """(loss per graph, prediction per graph); graph_ptr_i32 [B+1] int32 device tensor (rows of a graph are contiguous)."""
     return _ReadoutMseFn.apply(x, weight, bias, graph_ptr_i32, target, int(n))

@@ -17,6 +17,8 @@ gradient's dot product with a seeded Gaussian direction (both runs) plus, for pa
   model_motion.npz, model_nba.npz  (`make_model_golden.py motion nba`, round 3) the motion-capture and NBA task models
                     (motion_cssmpnn.py, nba_cssmpnn.py) in the same form as the two above.
   readout_hulls.npz (`make_model_golden.py readout`, round 3) the readout + loss stage of the hulls model on its own.
+  readout_md17.npz, readout_motion.npz, readout_nba.npz  (`make_model_golden.py traj_readout`, round 5) the head + loss
+                    statements of the three trajectory models on a seeded layer output.
   stages_hulls.npz / stages_md17.npz  (`make_model_golden.py stages [hulls md17]`, rounds 3 / 4) embedding output and x behind every EGCL layer of the
                     hulls model on model_hulls.npz's parameters and batch.
 The batches come from this repository's own PyG-free lift / collate (csmpn/data/complexes.py,
@@ -350,9 +352,99 @@ def make_readout():
     print("readout:", out["f32/loss"], out["f64/loss"])
 
 
+def make_traj_readout(kind):
+    """Round 5: readout_{md17,motion,nba}.npz - SURVEY.md §8(f)-2 for the trajectory models on its own: the reference model's
+    own `projection` module and the statements of its forward() behind the message passing (md17_cssmpnn.py:165-176,
+    motion_cssmpnn.py:150-168, nba_cssmpnn.py:176-191) on a seeded x [S, hidden, D] for the model fixture's batch: the loss
+    dictionary, d/dx whole, d/d(projection parameters) of sum_k sum(w_k * part_k) for seeded weights w (so that the MSE, ADE
+    and FDE paths all carry gradient), float64 (truth) and float32 (yardstick)."""
+    import torch.nn.functional as F
+    Model, batch = {"md17": (CliffordSharedSimplicialMPNN_md17, md17_batch(9)),
+                    "motion": (MotionCliffordSharedSimplicialMPNN, motion_batch(11)),
+                    "nba": (NBACliffordSharedSimplicialMPNN, nba_batch(13))}[kind]
+    out = {}
+    torch.manual_seed({"md17": 505, "motion": 606, "nba": 707}[kind])
+    model32 = Model()
+    save_batch(out, batch)
+    S = int(batch.node_types.shape[0])
+    C, D = {"md17": (32, 8), "motion": (16, 8), "nba": (40, 4)}[kind]
+    g = torch.Generator().manual_seed(17)
+    x0 = torch.randn(S, C, D, generator=g)
+    out["x"] = npy(x0)
+    proj = model32.projection
+    sd = {k: v for k, v in proj.state_dict().items() if "algebra." not in k}
+    gr = torch.Generator().manual_seed(19)
+    for k in sd:   # move a / b / bias off their 0 / 1 initial values
+        if k.split(".")[-1] in ("a", "b", "bias"):
+            sd[k] = sd[k] + 0.3 * torch.randn(sd[k].shape, generator=gr)
+    for k, v in sd.items():
+        out["p/" + k] = npy(v)
+    B = int(batch.ptr.shape[0]) - 1
+    for dt_name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dtype)
+        model = Model()
+        full = model.projection.state_dict()
+        for k, v in sd.items():
+            full[k] = v.to(dtype)
+        model.projection.load_state_dict(full, strict=True)
+        graph = namespace(batch, dtype)
+        x = x0.detach().clone().to(dtype).requires_grad_(True)
+        batch_size = B
+        if kind == "md17":        # md17_cssmpnn.py:149,165-176
+            num_frames = graph.loc.shape[1]
+            loc_node = graph.loc[graph.node_types == 0]
+            out_ = x[graph.node_types == 0]
+            pred = model.projection(out_)[..., 1:4]
+            loc_pred = loc_node + pred
+            targets = graph.y
+            ade_loss = torch.sqrt(F.mse_loss(loc_pred.reshape(-1, 3), targets.view(-1, 3), reduction="none").sum(dim=-1)).reshape(batch_size, -1, num_frames).mean(dim=-1).mean(dim=-1)
+            fde_loss = torch.sqrt(F.mse_loss(loc_pred[:, -1, :], targets[:, -1, :], reduction="none").sum(dim=-1)).reshape(batch_size, -1).mean(dim=-1)
+            loss = F.mse_loss(loc_pred.reshape(-1, 3), targets.view(-1, 3), reduction="none").reshape(batch_size, -1, 3).sum(-1).mean(-1)
+            parts = {"loss": loss, "ade_loss": ade_loss, "fde_loss": fde_loss}
+        elif kind == "motion":    # motion_cssmpnn.py:139,152-163 (node_pos = the positions before the mean is subtracted)
+            node_pos = graph.pos[graph.node_types == 0].reshape(batch_size, -1, 3)
+            out_ = x[graph.node_types == 0]
+            pred = model.projection(out_)[..., 0, 1:4]
+            pred = node_pos.reshape(-1, 3) + pred
+            targets = graph.y.view(-1, 3)
+            loss = F.mse_loss(pred, targets, reduction="none").mean(dim=1)
+            parts = {"loss": loss}
+        else:                     # nba_cssmpnn.py:176-188
+            num_frames = graph.pos.shape[1]
+            out_ = x[torch.where(graph.node_types == 0)]
+            out_ = model.projection(out_)
+            pred = out_[..., 1:3]
+            loc_pred = pred
+            loc_pred = loc_pred.reshape(batch_size, 6, num_frames * 4, -1)[:, :-1, ...]
+            loc_pred = loc_pred.reshape(-1, model.num_out, model.algebra.dim)
+            targets = graph.y
+            ade_loss = torch.sqrt(F.mse_loss(loc_pred.reshape(-1, model.algebra.dim), targets.view(-1, model.algebra.dim), reduction="none").sum(dim=-1)).reshape(batch_size, -1, num_frames).mean(dim=-1).mean(dim=-1)
+            fde_loss = torch.sqrt(F.mse_loss(loc_pred[:, -1, :], targets[:, -1, :], reduction="none").sum(dim=-1)).reshape(batch_size, -1).mean(dim=-1)
+            parts = {"loss": ade_loss, "ade_loss": ade_loss, "fde_loss": fde_loss}
+        gw = torch.Generator().manual_seed(23)
+        total = 0
+        for k in sorted(parts):
+            wk = torch.randn(parts[k].shape, generator=gw, dtype=torch.float32)
+            out[f"w/{k}"] = npy(wk)
+            total = total + (parts[k] * wk.to(dtype)).sum()
+            out[f"{dt_name}/{k}"] = npy(parts[k])
+        total.backward()
+        out[f"{dt_name}/gx"] = npy(x.grad).astype(np.float32)
+        for k, p in model.projection.named_parameters():
+            gg = p.grad if p.grad is not None else torch.zeros_like(p)
+            out[f"{dt_name}/g/{k}"] = npy(gg).astype(np.float64 if dt_name == "f64" else np.float32)
+        torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(HERE, f"readout_{kind}.npz"), **out)
+    print(f"readout {kind}:", {k: out[f'f64/{k}'][:3] for k in sorted(parts)})
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["readout"]:
         make_readout()
+        sys.exit(0)
+    if sys.argv[1:2] == ["traj_readout"]:
+        for kind in (sys.argv[2:] or ["md17", "motion", "nba"]):
+            make_traj_readout(kind)
         sys.exit(0)
     if sys.argv[1:2] == ["stages"]:
         for kind in (sys.argv[2:] or ["hulls"]):
