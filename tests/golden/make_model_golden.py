@@ -225,6 +225,28 @@ def make_hulls():
     np.savez_compressed(os.path.join(HERE, "traj_hulls.npz"), **tr)
 
 
+def make_fixed_traj():
+    """Round 5: traj_hulls_fixed.npz - 12 Adam steps (lr 1e-3, float32) of the reference hulls model on ONE batch (fixed
+    topology: what a HIP-graph replayed step needs), from model_hulls.npz's parameters and batch (seed 101 / hulls_batch(7)):
+    the losses. Pins csmpn_hip.graphed.GraphedTrainStep to the reference's own training loop
+    (engineer/trainer/trainer.py:204-227: zero_grad, forward, backward, step)."""
+    torch.manual_seed(101)
+    model = HullsCliffordSharedSimplicialMPNN()
+    batch = hulls_batch(7)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for step in range(12):
+        loss, _ = model(namespace(batch, torch.float32), step, "train")
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        print("fixed traj step", step, losses[-1], flush=True)
+    ref = np.load(os.path.join(HERE, "model_hulls.npz"))
+    assert abs(losses[0] - float(ref["f32/backprop_loss"])) <= 1e-6 * abs(losses[0])
+    np.savez_compressed(os.path.join(HERE, "traj_hulls_fixed.npz"), losses=np.asarray(losses, dtype=np.float64))
+
+
 def make_md17():
     out = {}
     torch.manual_seed(202)
@@ -441,6 +463,9 @@ def make_traj_readout(kind):
 if __name__ == "__main__":
     if sys.argv[1:] == ["readout"]:
         make_readout()
+        sys.exit(0)
+    if sys.argv[1:] == ["fixed_traj"]:
+        make_fixed_traj()
         sys.exit(0)
     if sys.argv[1:2] == ["traj_readout"]:
         for kind in (sys.argv[2:] or ["md17", "motion", "nba"]):

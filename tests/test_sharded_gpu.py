@@ -463,3 +463,86 @@ def test_rccl_world1_sharded_paths():
     assert res.pop("forced") == 0.0 and res.pop("fused") == 0.0
     for k, v in res.items():
         assert v < 5e-5, (k, v)
+
+
+def _worker_stack_reference(rank, world, port, q):
+    """The hulls model's three EGCL layers (parameters of model_hulls.npz) as a destination-partitioned stack over two ranks,
+    cuts aligned to the graphs of the batch, collectives in flight under the local-source edges, and the same chain replayed
+    from HIP-graph segments."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        pkg = importlib.import_module(PKG)
+        import test_model_harness as H
+        from csmpn.models import simplicial_mpnn as M
+        from csmpn_hip import sharded
+        dev = torch.device("cuda:0")
+        g = np.load(os.path.join(H.GOLD, "model_hulls.npz"))
+        model = H.build(pkg, "hulls", g, dev)
+        batch = H.load_batch(pkg, g, device=dev)
+        with torch.no_grad():
+            B, n = batch.num_graphs, model.algebra.dim
+            plan_b = batch.plan(model.max_dim)
+            vr = plan_b["vertex_rows"]
+            pos = batch.input.index_select(0, vr).reshape(B, -1, n)
+            inp = batch.input.index_copy(0, vr, (pos - pos.mean(dim=1, keepdim=True)).reshape(-1, n))
+            x0 = model._embed(batch, [(inp.unsqueeze(1), 1)])
+            types = torch.nn.functional.one_hot(batch.node_types, model.num_node_type).float()
+            node_attr, edge_attr = M.type_attributes(model.algebra, types, batch.edge_index)
+        N = int(batch.node_types.shape[0])
+        out = {}
+        for overlap in (False, True):
+            stack = sharded.DstPartitionedStack(list(model.layers), overlap=overlap)
+            plan = stack.plan(batch.edge_index, N, boundaries=batch.ptr)
+            eal = edge_attr[plan.edge_ids].contiguous()
+            with torch.no_grad():
+                out[f"stack_overlap{int(overlap)}"] = stack(x0, plan, eal, node_attr).cpu()
+        stack = sharded.DstPartitionedStack(list(model.layers))
+        plan = stack.plan(batch.edge_index, N, boundaries=batch.ptr)
+        eal = edge_attr[plan.edge_ids].contiguous()
+        step = sharded.GraphedDstStackStep(stack, plan, x0, eal, node_attr, torch.ones_like(x0))
+        step.run()
+        torch.cuda.synchronize()
+        out["graphed"] = step.out.detach().cpu()
+        q.put((rank, {k: v.numpy() for k, v in out.items()}, float(plan.local_share)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dst_stack_against_reference_stage_fixture():
+    """SURVEY.md §8(f)-4 pinned to the REFERENCE (round-4 review: the sharded / graphed multi-layer tests compared HIP with HIP):
+    the output of the hulls model's 3-layer chain computed by DstPartitionedStack (blocking and overlapped) and by
+    GraphedDstStackStep on two ranks equals x behind the reference model's last layer - stages_hulls.npz, recorded from the
+    imported reference (every 8th row whole, norm and a seeded projection of the full tensor; its float32 run = yardstick)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_model_harness as H
+    st = np.load(os.path.join(H.GOLD, "stages_hulls.npz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_stack_reference, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    k = "layer2"
+    rows64, rows32 = st[f"f64/{k}/rows"].astype(np.float64), st[f"f32/{k}/rows"].astype(np.float64)
+    scale = np.abs(rows64).max()
+    yard = np.abs(rows32 - rows64).max() / scale
+    n64, p64 = st[f"f64/{k}/np"]
+    n32, p32 = st[f"f32/{k}/np"]
+    for rank, outs, share in results:
+        assert share == 1.0            # graph-aligned cuts: no adjacency crosses ranks, the exchanges carry nothing needed
+        for name, t in outs.items():
+            err = np.abs(t[::8].astype(np.float64) - rows64).max() / scale
+            assert err <= max(1e-5, 4 * yard), (rank, name, err, yard)
+            tt = torch.from_numpy(t).double()
+            nrm, prj = float(tt.norm()), float((tt * H.direction_for(k, tt.shape)).sum())
+            assert abs(nrm - n64) <= max(1e-5, 4 * abs(n32 - n64) / n64) * n64, (rank, name, nrm, n64)
+            assert abs(prj - p64) <= max(1e-5, 4 * abs(p32 - p64) / n64) * n64, (rank, name, prj, p64)
