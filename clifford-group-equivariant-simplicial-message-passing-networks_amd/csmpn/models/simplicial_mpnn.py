@@ -42,6 +42,14 @@ def _fused_traj_readout(head, x) -> bool:
     return ops.readout_traj_supported(head, x)
 
 
+def _zero_grad_of(head):
+    """0 * sum(bias): the head's bias sits on blade 0 and does not reach the vector blades the fused readout reads - its
+    gradient is exactly zero, but it must EXIST: under DistributedDataParallel (the reference's multi-GPU mode,
+    csmpn/md17.py:15-20) a parameter without a gradient leaves its whole bucket un-reduced."""
+    b = getattr(head, "bias", None)
+    return 0.0 * b.sum() if b is not None else 0.0
+
+
 def segment_mean(x: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
     """global_mean_pool: mean of the rows of x per segment id (sum / clamp(count, 1))."""
     out = x.new_zeros((n,) + tuple(x.shape[1:]))
@@ -268,7 +276,7 @@ class MD17SimplicialMPNN(nn.Module):
             z = self.projection[0](x.index_select(0, vr))
             per_graph, _pv, _pred = ops.readout_traj(z, head.weight, loc_node, batch.y, plan["traj"], 3)
             loss = per_graph[:, 0]
-            return loss.mean(), {"loss": loss, "ade_loss": per_graph[:, 1], "fde_loss": per_graph[:, 2]}
+            return loss.mean() + _zero_grad_of(head), {"loss": loss, "ade_loss": per_graph[:, 1], "fde_loss": per_graph[:, 2]}
         pred = self.projection(x.index_select(0, vr))[..., 1:4]
         loc_pred = loc_node + pred
         tgt = batch.y
@@ -328,7 +336,7 @@ class MotionSimplicialMPNN(nn.Module):
             if "traj" not in plan:
                 plan["traj"] = ops.readout_traj_tables(plan["graph_of_vertex"], B, vertex_rows=vr, n_rows=x.shape[0])
             _pg, loss, _pred = ops.readout_traj(x, head.weight, node_pos, batch.y, plan["traj"], 3)
-            return loss.mean(), {"loss": loss}
+            return loss.mean() + _zero_grad_of(head), {"loss": loss}
         pred = node_pos + self.projection(x.index_select(0, vr))[..., 0, 1:4]
         loss = ((pred - batch.y.reshape(-1, 3)) ** 2).mean(dim=1)
         return loss.mean(), {"loss": loss}
@@ -400,7 +408,7 @@ class NBASimplicialMPNN(nn.Module):
                 plan["traj"] = ops.readout_traj_tables(plan["graph_of_vertex"], B, vertex_rows=vr, n_rows=x.shape[0], unscored_last=1)
             per_graph, _pv, _pred = ops.readout_traj(x, self.projection.weight, None, batch.y, plan["traj"], 2)
             ade = per_graph[:, 1]
-            return ade.mean(), {"loss": ade, "ade_loss": ade, "fde_loss": per_graph[:, 2]}
+            return ade.mean() + _zero_grad_of(self.projection), {"loss": ade, "ade_loss": ade, "fde_loss": per_graph[:, 2]}
         pred = self.projection(x.index_select(0, vr))[..., 1:3]                      # [V, num_out, 2]
         loc_pred = pred.reshape(B, self.agents, self.num_out, -1)[:, :-1].reshape(-1, self.num_out, 2)
         tgt = batch.y

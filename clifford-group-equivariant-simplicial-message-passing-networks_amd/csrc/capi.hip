@@ -20,6 +20,7 @@
 #include "cm_launch.hpp"
 #include "pl_launch.hpp"
 #include "plw_launch.hpp"
+#include "pg_launch.hpp"
 
 using namespace csmpn;
 
@@ -45,6 +46,7 @@ struct Switches {
     bool no_pl;          // CSMPN_NO_PL=1       8-channel Cl(5,0) / Cl(4,1) layers leave the parity-lane kernels (cemlp_pl.hpp)
     bool no_plw;         // CSMPN_NO_PLW=1      wide Cl(5,0) / Cl(4,1) layers leave the wide parity-lane kernels (cemlp_plw.hpp)
     bool plw8;           // CSMPN_PLW8=1        8 channels on the wide parity-lane kernels with one group
+    bool no_pg;          // CSMPN_NO_PG=1       24 / 28 / 32-channel Cl(5,0) / Cl(4,1) layers leave the 16-row-tile MFMA-mixing kernels (cemlp_pg.hpp)
     bool no_share;       // CSMPN_NO_SHARE=1    general kernels: z does not alias the input tile
     bool no_phased;      // CSMPN_NO_PHASED=1   general kernels: backward of all blocks per tile instead of block by block
     bool no_sliced;      // CSMPN_NO_SLICED_GRADS=1  general kernels: parameter-gradient atomics onto one copy
@@ -70,6 +72,7 @@ const Switches& sw() {
         Switches r;
         r.no_cl = flag("CSMPN_NO_CL"); r.no_cm = flag("CSMPN_NO_CM"); r.no_cm_bwd = flag("CSMPN_NO_CM_BWD");
         r.no_pl = flag("CSMPN_NO_PL"); r.no_plw = flag("CSMPN_NO_PLW"); r.plw8 = flag("CSMPN_PLW8");
+        r.no_pg = flag("CSMPN_NO_PG");
         r.no_share = flag("CSMPN_NO_SHARE"); r.no_phased = flag("CSMPN_NO_PHASED"); r.no_sliced = flag("CSMPN_NO_SLICED_GRADS");
         r.debug = getenv("CSMPN_DEBUG") != nullptr;
         r.force_ps = getenv("CSMPN_FORCE_PS") ? (atoi(getenv("CSMPN_FORCE_PS")) != 0) : -1;
@@ -706,7 +709,8 @@ size_t plw_table_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (ch < 8 || ch > 32) return 0;
     if (nblk == 2 && (blocks[1].out_features != ch || blocks[1].in_features != ch)) return 0;
     const size_t NG = (ch + 7) / 8, nch0 = 2 * NG + 1;
-    return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256 + plw_part_bytes(ch);
+    // (+ 64 KB: the weight-fragment tables of cemlp_pg.hpp, carved from the same region, are up to 368 KB at 28 / 32 channels)
+    return ((2 * NG * nch0 + 4 * NG * NG) + (2 * NG * NG + 4 * NG * NG)) * 384 * sizeof(float) + 256 + plw_part_bytes(ch) + (ch > 16 ? 65536 : 0);
 }
 
 // (row, channel)-per-lane kernels (cemlp_cl.hpp): Cl(3,0), two blocks of 8 channels, the EGCL attribute widths of S1.
@@ -811,10 +815,61 @@ bool plw_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& i
     return true;
 }
 
+// 16-row-tile MFMA-mixing kernels (cemlp_pg.hpp): Cl(5,0) / Cl(4,1), two blocks of 24 / 28 / 32 channels, EGCL edge / node programs
+bool pg_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
+    if (sw().no_pg || (id != ALG_N5 && id != ALG_N5M)) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    const int ch = C.b[0].O;
+    if (ch <= 16 || ch > 32 || !C.b[0].w1_sub || C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub) return false;
+    int na = 0;
+    if (mode == MODE_EDGE) {
+        if (io.seg[0].ch != ch) return false;
+        na = io.nseg > 1 ? io.seg[1].ch : 0;
+        if (C.b[0].I != ch + na) return false;
+    } else if (mode == MODE_NODE) {
+        if (io.seg[0].ch != ch || io.seg[1].ch != ch) return false;
+        na = io.nseg > 2 ? io.seg[2].ch : 0;
+        if (C.b[0].I != 2 * ch + na) return false;
+    } else {
+        return false;
+    }
+    if (!(id == ALG_N5 ? has_cemlp_pg_n5(mode, ch, na, bwd) : has_cemlp_pg_n5m(mode, ch, na, bwd))) return false;
+    const size_t tf = id == ALG_N5 ? cemlp_pg_table_floats_n5(mode, ch, na) : cemlp_pg_table_floats_n5m(mode, ch, na);
+    if (tf == 0 || !plan.workspace || plan.workspace_bytes < tf * sizeof(float) + plw_part_bytes(ch) + 1024) return false;
+    // the backward of this family runs on the state its forward saved (CSMPN_FLAG_SAVE_STATE, in ITS lane order): without
+    // the flag the forward still serves (it writes the row-major block-1 inputs every backward reads) and the wide
+    // parity-lane backward recomputes from them
+    if (bwd && !(io.saved && io.save_state)) return false;
+    *channels = ch;
+    *attr = na;
+    return true;
+}
+
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st, bool need_pack) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    {
+        int channels = 0, attr = 0;
+        if (pg_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
+            const long tiles = (io.rows + 15) / 16;          // one 16-row tile per workgroup iteration, one 8-wave workgroup per CU
+            const unsigned grid = (unsigned)(tiles < 256 ? tiles : 256);
+            const size_t tb = (id == ALG_N5 ? cemlp_pg_table_floats_n5(mode, channels, attr) : cemlp_pg_table_floats_n5m(mode, channels, attr)) * sizeof(float);
+            float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
+            io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - plw_part_bytes(channels));
+            if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // hand-over rows behind the saved block inputs
+            bool handled = false;
+            if (sw().debug) fprintf(stderr, "[csmpn] pg mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
+            if (id == ALG_N5) HIP_TRY(launch_cemlp_pg_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            else HIP_TRY(launch_cemlp_pg_n5m(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            if (handled) {
+                note_kernel("csmpn::cemlp_pg_%s_kernel<%s, ...> (mode %d, %d channels, %d attribute channels)", bwd ? "bwd" : "fwd",
+                            alg_name(id), mode, channels, attr);
+                return CSMPN_OK;
+            }
+        }
+    }
     {
         int channels = 0, attr = 0;
         if (plw_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
@@ -1223,7 +1278,8 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
 static size_t state_channels(int n, const csmpn_block_params* blocks, int n_blocks) {
     if (n_blocks != 2) return 0;
     const size_t ch = (size_t)blocks[0].out_features;
-    if (plw_table_bytes(n, blocks, n_blocks)) return (size_t)3 * n_blocks * ((ch + 7) / 8 * 8);
+    // (17 .. 32 channels: 32 - the 16-row-tile kernels of cemlp_pg.hpp keep 4 channels per wave, 8 waves per tile)
+    if (plw_table_bytes(n, blocks, n_blocks)) return (size_t)3 * n_blocks * (ch > 16 ? 32 : (ch + 7) / 8 * 8);
     if (cl_shape(n, blocks, n_blocks)) {
         if (has_cemlp_cl_n3(MODE_EDGE, n_blocks, (int)ch, blocks[0].in_features) || has_cemlp_cl_n3(MODE_NODE, n_blocks, (int)ch, blocks[0].in_features))
             return (size_t)n_blocks * ch;
