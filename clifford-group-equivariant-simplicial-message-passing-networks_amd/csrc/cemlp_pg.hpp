@@ -128,7 +128,7 @@ struct PgCfg {
     static constexpr int slice_max = slice_floats(0) > slice_floats(1) ? slice_floats(0) : slice_floats(1);
     // backward LDS (floats): A | B | E (8 slots: attribute chunk) | two row-sum arrays | path weights and parameters of ONE block | indices
     static constexpr int b_E = 2 * kPgBuf, b_ln = b_E + 8 * kPgCS, b_w = b_ln + 2 * kPgRows * 32, b_par = b_w + 32 * P,
-                         b_idx = b_par + 32 * par_stride, bwd_lds_floats = b_idx + 64;
+                         b_idx = b_par + 32 * par_stride, bwd_lds_floats = b_idx + 128;
     static_assert(bwd_lds_floats * 4 <= 160 * 1024, "LDS footprint of the backward");
     // LDS (floats)
     static constexpr int o_A = 0, o_B = kPgBuf, o_E = 2 * kPgBuf;                 // E: 4 slots (node attributes)
@@ -808,8 +808,10 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
     float* const bufE = smem + CF::b_E;
     float* const ln1 = smem + CF::b_ln;
     float* const ln2 = ln1 + kPgRows * 32;
-    int* const sidx = reinterpret_cast<int*>(smem + CF::b_idx);
-    float* const sscale = smem + CF::b_idx + 48;
+    int* sidx = reinterpret_cast<int*>(smem + CF::b_idx);          // this tile's [0..15] targets, [16..31] sources, [32..47] attribute rows,
+    int* sidx_n = sidx + 64;                                        // [48..63] 1 / max(deg, 1) as float; the next tile's in the other half
+    constexpr int NPRE = PPR * kPgRows / kPgThreads;               // 16-byte pieces of a C-channel tile per thread
+    static_assert(NPRE * kPgThreads == PPR * kPgRows, "whole pieces per thread");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, c = 4 * wave + (lane >> 4), l16 = lane & 15;
     const bool cvalid = c < C;
@@ -837,46 +839,64 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
 #pragma unroll
     for (int g = 0; g < 3; ++g) accL[g] = accR[g] = accW0[g] = accW1[g] = accW2[g] = f4{0.f, 0.f, 0.f, 0.f};
     float small[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    stamp(0);
-
     const long ntiles = (io.rows + kPgRows - 1) / kPgRows;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row0 = tile * kPgRows;
-        {
-        PG_PHASE_IDS();
-        if (tid < kPgRows) {
-            const long row = row0 + tid;
-            const bool valid = row < io.rows;
-            if constexpr (MODE == MODE_EDGE) {
-                sidx[tid] = valid ? io.seg[0].ia[row] : -1;
-                sidx[16 + tid] = valid ? io.seg[0].ib[row] : 0;
-                sidx[32 + tid] = valid ? io.seg[1].ia[row] : 0;
-            } else {
-                sidx[tid] = valid ? (int)tid : -1;
-                float sc = 1.0f;
-                if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
-                sscale[tid] = sc;
-            }
+    // Software pipeline over the workgroup's tiles: the indices of tile t + 1 are fetched while tile t computes, its d/d(out)
+    // rows are requested in front of tile t's row stores / atomics (few registers are alive there) and written to LDS at the
+    // top of tile t + 1; the state rows of a phase are requested one phase ahead.
+    auto load_idx = [&](int* dst, long tile_, int t) {     // threads 0 .. 15
+        const long row = tile_ * kPgRows + t;
+        const bool valid = tile_ < ntiles && row < io.rows;
+        if constexpr (MODE == MODE_EDGE) {
+            dst[t] = valid ? io.seg[0].ia[row] : -1;
+            dst[16 + t] = valid ? io.seg[0].ib[row] : 0;
+            dst[32 + t] = valid ? io.seg[1].ia[row] : 0;
+        } else {
+            dst[t] = valid ? t : -1;
+            float sc = 1.0f;
+            if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            reinterpret_cast<float*>(dst)[48 + t] = sc;
         }
-        }
-        __syncthreads();
-        // ---- d/d(block output) rows -> A
-        {
-        PG_PHASE_IDS();
-        for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
-            const int rr = p / PPR, e = p % PPR;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
-            if (sidx[rr] >= 0) {
+    };
+    f4 pre[NPRE];
+    auto issue_gout = [&](const int* idx, long tile_, int t) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int p = t + i * kPgThreads, rr = p / PPR, e = p % PPR;
+            pre[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (idx[rr] >= 0) {
                 if constexpr (K == 1) {
-                    const size_t grow = MODE == MODE_EDGE ? (size_t)sidx[rr] : (size_t)(row0 + rr);
-                    v = pg_ld4(io.gy + grow * ROW + 4 * e);
+                    const size_t grow = MODE == MODE_EDGE ? (size_t)idx[rr] : (size_t)(tile_ * kPgRows + rr);
+                    pre[i] = pg_ld4(io.gy + grow * ROW + 4 * e);
                 } else {
-                    v = pg_ld4(io.plw_g1 + (size_t)(row0 + rr) * ROW + 4 * e);
+                    pre[i] = pg_ld4(io.plw_g1 + (size_t)(tile_ * kPgRows + rr) * ROW + 4 * e);
                 }
             }
-            pg_st4(bufA + pg_off(e >> 3, rr, e & 7), v);
         }
+    };
+    if (threadIdx.x < kPgRows) load_idx(sidx, blockIdx.x, threadIdx.x);
+    __syncthreads();
+    issue_gout(sidx, blockIdx.x, threadIdx.x);
+    stamp(0);
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * kPgRows;
+        const float* const sscale = reinterpret_cast<const float*>(sidx) + 48;
+        float s_st[32], y_st[32];     // state rows of the first ROW phase, requested in front of the staging barrier
+        {
+        PG_PHASE_IDS();
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { s_st[d] = 0.f; y_st[d] = 0.f; }
+        if (live) {
+            pg_load_state(s_st, io.saved + state_region<ROW, ROWP>(io.rows, 0, K) + soff);
+            pg_load_state(y_st, io.saved + state_region<ROW, ROWP>(io.rows, 1, K) + soff);
+        }
+        // ---- d/d(block output) rows (requested during the previous tile) -> A
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int p = tid + i * kPgThreads, rr = p / PPR, e = p % PPR;
+            pg_st4(bufA + pg_off(e >> 3, rr, e & 7), pre[i]);
+        }
+        if (tid < kPgRows) load_idx(sidx_n, tile + gridDim.x, tid);
         }
         __syncthreads();
         stamp(1);
@@ -885,14 +905,9 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         float g_la, g_bL;
         {
             PG_PHASE_IDS();
-            float s[32], y[32];
+            float (&s)[32] = s_st;
+            float (&y)[32] = y_st;
             pg_ld32(ggp, bufA, r, c);     // d/d(out)
-#pragma unroll
-            for (int d = 0; d < 32; ++d) { s[d] = 0.f; y[d] = 0.f; }
-            if (live) {
-                pg_load_state(s, io.saved + state_region<ROW, ROWP>(io.rows, 0, K) + soff);
-                pg_load_state(y, io.saved + state_region<ROW, ROWP>(io.rows, 1, K) + soff);
-            }
             static_for<0, G>([&](auto g) {
                 constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
                 float u;
@@ -945,8 +960,12 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         __syncthreads();
         stamp(2);
         // ---- MIX: gz = WL^T ggp (this wave's 4 blades), d/dWL tile += ggp^T z; then gz over ggp in B
+        float R_st[32];               // the next ROW phase's state rows travel under the MFMAs
         {
             PG_PHASE_IDS();
+#pragma unroll
+            for (int d = 0; d < 32; ++d) R_st[d] = 0.f;
+            if (live) pg_load_state(R_st, io.saved + state_region<ROW, ROWP>(io.rows, 2, K) + soff);
             f4 acc[4][2];
             pg_zero(acc);
             pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mL), lane, wave);
@@ -961,12 +980,10 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         PgCollect col;
         {
             PG_PHASE_IDS();
-            float z[32], R[32];
+            float z[32];
+            float (&R)[32] = R_st;
             pg_ld32(gz, bufB, r, c);
             pg_ld32(z, bufA, r, c);
-#pragma unroll
-            for (int d = 0; d < 32; ++d) R[d] = 0.f;
-            if (live) pg_load_state(R, io.saved + state_region<ROW, ROWP>(io.rows, 2, K) + soff);
             float invden[G], den[G], nu[G], qR[G];
             static_for<0, G>([&](auto g) {
                 constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
@@ -1017,8 +1034,12 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         __syncthreads();
         stamp(4);
         // ---- MIX: WR^T gR, d/dWR tile += gR^T z; the result over gR in B
+        float y2_st[32];
         {
             PG_PHASE_IDS();
+#pragma unroll
+            for (int d = 0; d < 32; ++d) y2_st[d] = 0.f;
+            if (live) pg_load_state(y2_st, io.saved + state_region<ROW, ROWP>(io.rows, 1, K) + soff);
             f4 acc[4][2];
             pg_zero(acc);
             pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mR), lane, wave);
@@ -1028,18 +1049,23 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         }
         __syncthreads();
         stamp(5);
-        // ---- block input -> A (+ E): z has been read for the last time. Coalesced pieces, all threads.
+        // ---- block input -> A (+ E): z has been read for the last time. Coalesced pieces, all threads; the rows are
+        // requested here and written behind the MVSiLU backward
+        f4 xa[NPRE], xb[K == 0 && MODE == MODE_EDGE ? NPRE : 1];
         {
         PG_PHASE_IDS();
-        for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
-            const int rr = p / PPR, e = p % PPR;
-            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int p = tid + i * kPgThreads, rr = p / PPR, e = p % PPR;
+            xa[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (K == 0 && MODE == MODE_EDGE) xb[i] = f4{0.f, 0.f, 0.f, 0.f};
             if (sidx[rr] >= 0) {
-                if constexpr (K == 1) v = pg_ld4(io.saved + (size_t)(row0 + rr) * ROW + 4 * e);
-                else if constexpr (MODE == MODE_EDGE) v = pg_ld4(io.seg[0].a + (size_t)sidx[rr] * ROW + 4 * e) - pg_ld4(io.seg[0].b + (size_t)sidx[16 + rr] * ROW + 4 * e);
-                else v = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
+                if constexpr (K == 1) xa[i] = pg_ld4(io.saved + (size_t)(row0 + rr) * ROW + 4 * e);
+                else if constexpr (MODE == MODE_EDGE) {
+                    xa[i] = pg_ld4(io.seg[0].a + (size_t)sidx[rr] * ROW + 4 * e);
+                    xb[i] = pg_ld4(io.seg[0].b + (size_t)sidx[16 + rr] * ROW + 4 * e);
+                } else xa[i] = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
             }
-            pg_st4(bufA + pg_off(e >> 3, rr, e & 7), v);
         }
         if constexpr (K == 0) {
             constexpr int PPA = 16 * 8;   // one 16-channel tile of attribute slots (the rows-contracting MFMA reads all of them)
@@ -1057,11 +1083,11 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         // ---- ROW: MVSiLU backward -> gy -> B
         {
             PG_PHASE_IDS();
-            float t_[32], y[32];
+            float t_[32];
+            float (&y)[32] = y2_st;
             pg_ld32(t_, bufB, r, c);
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { gz[d] += t_[d]; y[d] = 0.f; }
-            if (live) pg_load_state(y, io.saved + state_region<ROW, ROWP>(io.rows, 1, K) + soff);
+            for (int d = 0; d < 32; ++d) gz[d] += t_[d];
             static_for<0, G>([&](auto g) {
                 constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
                 float u, ggate = 0.f;
@@ -1094,6 +1120,12 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
             col.template add<78>(g_bL, small, l16);
             col.template add<79>(0.f, small, l16);
             pg_st32(bufB, r, c, gz);
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int p = tid + i * kPgThreads, rr = p / PPR, e = p % PPR;
+                if constexpr (K == 0 && MODE == MODE_EDGE) xa[i] -= xb[i];
+                pg_st4(bufA + pg_off(e >> 3, rr, e & 7), xa[i]);
+            }
         }
         __syncthreads();
         stamp(6);
@@ -1149,9 +1181,11 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         }
         __syncthreads();
         stamp(7);
-        // ---- rows out
+        // ---- rows out; the next tile's d/d(out) rows are requested first (vmcnt counts in order: behind the atomics
+        // they would wait for their acknowledgement)
         {
         PG_PHASE_IDS();
+        issue_gout(sidx_n, tile + gridDim.x, tid);
         if constexpr (K == 1) {
             for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
                 const int rr = p / PPR, e = p % PPR;
@@ -1212,6 +1246,7 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
         }
         }
         __syncthreads();
+        { int* t_ = sidx; sidx = sidx_n; sidx_n = t_; }
         stamp(8);
     }
     // ---- this workgroup's slice: every element has one owner

@@ -16,6 +16,10 @@ FWD = ["prologue", "tile bookkeeping + input staging (+barrier)", "b0 MIX W1", "
        "rows out / scatter"]
 
 
+BWD = ["prologue", "bookkeeping + d/d(out) staging (+barrier)", "ROW z, layer-norm backward -> ggp", "MIX WL^T + d/dWL", "ROW gp + norm backward",
+       "MIX WR^T + d/dWR", "input staging + ROW silu backward", "MIX W1^T + d/dW1", "rows out / scatter", "slice store"]
+
+
 def main(workload="H28", which="edge_fwd"):
     dev = torch.device("cuda:0")
     metric, C, N, E = bench.WORKLOADS[workload]
@@ -30,7 +34,12 @@ def main(workload="H28", which="edge_fwd"):
     csr = ops.get_csr(ei, N)
     pe, pn = layer.edge_model.flat_params(), layer.node_model.flat_params()
     agg, se = be.edge_forward(spec, csr, h, ea, pe)
-    stages = {"edge_fwd": lambda: be.edge_forward(spec, csr, h, ea, pe), "node_fwd": lambda: be.node_forward(spec, csr.deg, h, agg, na, pn)}
+    out, sn = be.node_forward(spec, csr.deg, h, agg, na, pn)
+    gout = torch.ones_like(out)
+    gh, g_agg, _, _ = be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, sn)
+    stages = {"edge_fwd": lambda: be.edge_forward(spec, csr, h, ea, pe), "node_fwd": lambda: be.node_forward(spec, csr.deg, h, agg, na, pn),
+              "node_bwd": lambda: be.node_backward(spec, csr.deg, h, agg, na, pn, gout, False, sn),
+              "edge_bwd": lambda: be.edge_backward(spec, csr, h, ea, pe, g_agg, gh, False, se)}
     for name, fn in stages.items():
         fn(); torch.cuda.synchronize()
         st.zero_(); torch.cuda.synchronize()
@@ -40,7 +49,7 @@ def main(workload="H28", which="edge_fwd"):
         v = st.cpu().tolist()
         waves, tot = v[24], sum(v[:24])
         print(f"== {name}: {waves} waves, {tot / max(waves,1) / 1e3:.1f} kcycles per wave  [{lib.csmpn_last_kernel().decode()}]")
-        for i, nm in enumerate(FWD):
+        for i, nm in enumerate(FWD if name.endswith("fwd") else BWD):
             if v[i]:
                 print(f"   {nm:48s} {v[i] / waves / 1e3:9.1f} kcyc  {100.0 * v[i] / tot:5.1f}%")
 
