@@ -100,10 +100,30 @@ def pmc_traffic(stage, workload, kernel_name=None):
     if not found:
         return None, None
     norm = lambda n: n.replace("void ", "").split("(")[0].replace(" ", "")
+    import re
     try:
         with open(found[-1]) as f:
+            summary = json.load(f)
+        # families whose entry point reports an abbreviated name ("csmpn::cemlp_pg_bwd_kernel<Alg, ...> (mode M, ...)": the wide
+        # D = 32 kernels) run a stage as SEVERAL launches (one per block): the stage's traffic is the sum over the launches
+        # of that family and mode in the summary
+        m = re.match(r"(csmpn::cemlp_(plw|pg)_(fwd|bwd)_kernel)<.*\.\.\.>\s*\(mode (\d)", kernel_name or "")
+        if m:
+            fam, which, mode = m.group(1), m.group(2), m.group(4)
+            total = 0
+            for name, c in summary.items():
+                if fam + "<" not in name.replace("void ", "") or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                    continue
+                cfg = re.search(r"P(lw|g)Cfg<csmpn::Alg<[^>]*>, ([^>]*)>", name)
+                if not cfg:
+                    continue
+                args = [a_.strip() for a_ in cfg.group(2).split(",")]
+                if args[2 if which == "plw" else 1] == mode:
+                    total += int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+            return (total, os.path.relpath(found[-1], ROOT)) if total else (None, None)
+        if True:
             best = None
-            for name, c in json.load(f).items():
+            for name, c in summary.items():
                 if kernel_name is not None and norm(name) != norm(kernel_name):
                     continue
                 if kernel_of(stage, name) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:

@@ -136,7 +136,7 @@ struct PgCfg {
     static constexpr int o_w = o_ln + kPgRows * 32;                               // path weights [2 blocks][32 channels][P]
     static constexpr int o_par = o_w + 2 * 32 * P;
     static constexpr int o_idx = o_par + 2 * 32 * par_stride;                    // 3 x 16 ints (targets, sources, attribute rows) + 16 floats
-    static constexpr int lds_floats = o_idx + 64;
+    static constexpr int lds_floats = o_idx + 128;
     static_assert(lds_floats * 4 <= 160 * 1024, "LDS footprint");
 };
 
@@ -365,8 +365,11 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
     float* const bufB = smem + CF::o_B;
     float* const bufE = smem + CF::o_E;
     float* const lnx = smem + CF::o_ln;
-    int* const sidx = reinterpret_cast<int*>(smem + CF::o_idx);      // [0..15] target / row, [16..31] source, [32..47] attribute row
-    float* const sscale = smem + CF::o_idx + 48;                     // node program: 1 / max(deg, 1)
+    int* sidx = reinterpret_cast<int*>(smem + CF::o_idx);            // this tile's [0..15] target / row, [16..31] source, [32..47] attribute row,
+    int* sidx_n = sidx + 64;                                          // [48..63] node program: 1 / max(deg, 1) (float); the next tile's in the other half
+    constexpr int PPR = C * 8, PPA = 4 * CF::NSTA * 8;                // 16-byte pieces per row: a C-channel segment, the attribute chunk padded to whole k-steps
+    constexpr int NPRE = PPR * kPgRows / kPgThreads, NPA = (PPA * kPgRows + kPgThreads - 1) / kPgThreads;
+    static_assert(NPRE * kPgThreads == PPR * kPgRows, "whole pieces per thread");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = lane & 15, c = 4 * wave + (lane >> 4);             // ROW layout
     const bool cvalid = c < C;
@@ -399,57 +402,78 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
     }
     __syncthreads();
 
-    stamp(0);
     const bool save_state = io.save_state != 0 && io.save != nullptr;
     const long ntiles = (io.rows + kPgRows - 1) / kPgRows;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long row0 = tile * kPgRows;
-        // ---- tile bookkeeping
-        if (tid < kPgRows) {
-            const long row = row0 + tid;
-            const bool valid = row < io.rows;
-            if constexpr (MODE == MODE_EDGE) {
-                sidx[tid] = valid ? io.seg[0].ia[row] : -1;
-                sidx[16 + tid] = valid ? io.seg[0].ib[row] : 0;
-                sidx[32 + tid] = valid ? io.seg[1].ia[row] : 0;
-            } else {
-                sidx[tid] = valid ? (int)tid : -1;
-                float sc = 1.0f;
-                if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
-                sscale[tid] = sc;
+    // Software pipeline over the workgroup's tiles: the indices of tile t + 1 are fetched while tile t computes; its input rows
+    // are requested in front of tile t's row stores / atomics (few registers are alive there; vmcnt counts in issue order, a load
+    // behind an atomic would wait for its acknowledgement) and written to LDS at the top of tile t + 1.
+    auto load_idx = [&](int* dst, long tile_, int t) {     // threads 0 .. 15
+        const long row = tile_ * kPgRows + t;
+        const bool valid = tile_ < ntiles && row < io.rows;
+        if constexpr (MODE == MODE_EDGE) {
+            dst[t] = valid ? io.seg[0].ia[row] : -1;
+            dst[16 + t] = valid ? io.seg[0].ib[row] : 0;
+            dst[32 + t] = valid ? io.seg[1].ia[row] : 0;
+        } else {
+            dst[t] = valid ? t : -1;
+            float sc = 1.0f;
+            if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            reinterpret_cast<float*>(dst)[48 + t] = sc;
+        }
+    };
+    f4 pre_a[NPRE], pre_b[NPRE], pre_x[NPA];
+    auto issue_rows = [&](const int* idx, long tile_, int t) {
+        const float* sc_ = reinterpret_cast<const float*>(idx) + 48;
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int p = t + i * kPgThreads, rr = p / PPR, e = p % PPR;
+            pre_a[i] = pre_b[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (idx[rr] >= 0) {
+                if constexpr (MODE == MODE_EDGE) {
+                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)idx[rr] * ROW + 4 * e);
+                    pre_b[i] = pg_ld4(io.seg[0].b + (size_t)idx[16 + rr] * ROW + 4 * e);
+                } else {
+                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)(tile_ * kPgRows + rr) * ROW + 4 * e);
+                    pre_b[i] = pg_ld4(io.seg[1].a + (size_t)(tile_ * kPgRows + rr) * ROW + 4 * e) * sc_[rr];
+                }
             }
         }
-        __syncthreads();
-        // ---- block-0 input chunks -> LDS: 16-byte pieces, consecutive threads = consecutive pieces of a row (coalesced)
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int p = t + i * kPgThreads, rr = (p / PPA) & 15, e = p % PPA;
+            pre_x[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if (p < kPgRows * PPA && idx[rr] >= 0 && e < NA * 8) {
+                if constexpr (MODE == MODE_EDGE) pre_x[i] = pg_ld4(io.seg[1].a + (size_t)idx[32 + rr] * (NA * D) + 4 * e);
+                else pre_x[i] = pg_ld4(io.seg[2].a + (size_t)(tile_ * kPgRows + rr) * (NA * D) + 4 * e);
+            }
+        }
+    };
+    if (tid < kPgRows) load_idx(sidx, blockIdx.x, tid);
+    __syncthreads();
+    issue_rows(sidx, blockIdx.x, tid);
+    stamp(0);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long row0 = tile * kPgRows;
+        // ---- block-0 input chunks (requested during the previous tile) -> LDS: 16-byte pieces, consecutive threads =
+        // consecutive pieces of a row (coalesced)
         {
-            constexpr int PPR = C * 8;   // pieces per row
-            for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
-                const int rr = p / PPR, e = p % PPR;
-                const int t_ = sidx[rr];
-                f4 v = f4{0.f, 0.f, 0.f, 0.f};
-                if (t_ >= 0) {
-                    if constexpr (MODE == MODE_EDGE) {
-                        v = pg_ld4(io.seg[0].a + (size_t)t_ * ROW + 4 * e) - pg_ld4(io.seg[0].b + (size_t)sidx[16 + rr] * ROW + 4 * e);
-                    } else {
-                        v = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
-                        pg_st4(bufB + pg_off(e >> 3, rr, e & 7), pg_ld4(io.seg[1].a + (size_t)(row0 + rr) * ROW + 4 * e) * sscale[rr]);
-                    }
-                } else if constexpr (MODE == MODE_NODE) {
-                    pg_st4(bufB + pg_off(e >> 3, rr, e & 7), v);
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int p = tid + i * kPgThreads, rr = p / PPR, e = p % PPR;
+                if constexpr (MODE == MODE_EDGE) {
+                    pg_st4(bufA + pg_off(e >> 3, rr, e & 7), pre_a[i] - pre_b[i]);
+                } else {
+                    pg_st4(bufA + pg_off(e >> 3, rr, e & 7), pre_a[i]);
+                    pg_st4(bufB + pg_off(e >> 3, rr, e & 7), pre_b[i]);
                 }
-                pg_st4(bufA + pg_off(e >> 3, rr, e & 7), v);
             }
-            constexpr int PPA = 4 * CF::NSTA * 8;   // attribute pieces per row, padded to whole k-steps
             float* const bufX = MODE == MODE_EDGE ? bufB : bufE;
-            for (int p = tid; p < kPgRows * PPA; p += kPgThreads) {
-                const int rr = p / PPA, e = p % PPA;
-                f4 v = f4{0.f, 0.f, 0.f, 0.f};
-                if (sidx[rr] >= 0 && e < NA * 8) {
-                    if constexpr (MODE == MODE_EDGE) v = pg_ld4(io.seg[1].a + (size_t)sidx[32 + rr] * (NA * D) + 4 * e);
-                    else v = pg_ld4(io.seg[2].a + (size_t)(row0 + rr) * (NA * D) + 4 * e);
-                }
-                pg_st4(bufX + pg_off(e >> 3, rr, e & 7), v);
+#pragma unroll
+            for (int i = 0; i < NPA; ++i) {
+                const int p = tid + i * kPgThreads, rr = (p / PPA) & 15, e = p % PPA;
+                if (p < kPgRows * PPA) pg_st4(bufX + pg_off(e >> 3, rr, e & 7), pre_x[i]);
             }
+            if (tid < kPgRows) load_idx(sidx_n, tile + gridDim.x, tid);
         }
         __syncthreads();
         stamp(1);
@@ -475,7 +499,6 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
                     pg_mix_acc<NST>(acc, bufB, tabs + CF::toff(1, 0), lane, wave);
                     // the block-1 input rows leave for the backward (coalesced, while the MFMAs run)
                     if (io.save) {
-                        constexpr int PPR = C * 8;
                         for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
                             const int rr = p / PPR, e = p % PPR;
                             if (row0 + rr < io.rows) pg_st4(io.save + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufB + pg_off(e >> 3, rr, e & 7)));
@@ -578,10 +601,10 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
             stamp(7 + 6 * K);
         });
 
-        // ---- rows leave through A
+        // ---- rows leave through A; the next tile's input rows are requested first
+        issue_rows(sidx_n, tile + gridDim.x, tid);
         if constexpr (MODE == MODE_EDGE) {
             if (io.row_store) {   // deterministic mode: message rows to the [E, C, D] table in sorted edge order
-                constexpr int PPR = C * 8;
                 for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
                     const int rr = p / PPR, e = p % PPR;
                     if (row0 + rr < io.rows) pg_st4(io.agg + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufA + pg_off(e >> 3, rr, e & 7)));
@@ -606,7 +629,6 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
                 }
             }
         } else {
-            constexpr int PPR = C * 8;
             for (int p = tid; p < kPgRows * PPR; p += kPgThreads) {
                 const int rr = p / PPR, e = p % PPR;
                 if (row0 + rr < io.rows) {
@@ -617,6 +639,7 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_fwd_kernel(const DevCe
             }
         }
         __syncthreads();   // A / B / the index arrays are free for the next tile
+        { int* t_ = sidx; sidx = sidx_n; sidx_n = t_; }
         stamp(14);
     }
     stamp.flush(io.stamps, lane);
@@ -1272,27 +1295,34 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
 }
 
 // grads += sum over the workgroups' slices, fixed order (one thread per slice element)
+// A workgroup takes 64 consecutive elements; thread (j = tid & 63, q = tid >> 6) sums the slices q, q + 4, ... (16 loads in
+// flight, compensated), the four partial sums of an element meet in LDS and are added in order.
 template <class ALG, class CF, int K>
 __global__ void __launch_bounds__(256) pg_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
     constexpr int C = CF::C, G = 6, P = CF::P, SF = CF::slice_floats(K), SW = CF::slice_w(K);
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= SF) return;
-    // compensated (Kahan) sum over up to 256 slices: the slices of a large launch cancel heavily on indefinite metrics
+    __shared__ float red[4][64];
+    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + j;
+    // compensated (Kahan) sums: the slices of a large launch cancel heavily on indefinite metrics
     float s = 0.f, comp = 0.f;
     auto add = [&](float v) {
         const float yk = v - comp, t = s + yk;
         comp = (t - s) - yk;
         s = t;
     };
-    int sl = 0;
-    for (; sl + 8 <= nslices; sl += 8) {
-        float v[8];
+    if (e < SF) {
+        for (int sl = q; sl < nslices; sl += 64) {
+            float v[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = part[(size_t)(sl + i) * SF + e];
+            for (int i = 0; i < 16; ++i) v[i] = sl + 4 * i < nslices ? part[(size_t)(sl + 4 * i) * SF + e] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) add(v[i]);
+            for (int i = 0; i < 16; ++i) add(v[i]);
+        }
     }
-    for (; sl < nslices; ++sl) add(part[(size_t)sl * SF + e]);
+    red[q][j] = s;
+    __syncthreads();
+    if (q != 0 || e >= SF) return;
+    s = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
     const DevBlock& B = Cd.b[K];
     if (e < SW) {
         int m = 0, f = e;
