@@ -991,8 +991,15 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
             if (live) pg_load_state(R_st, io.saved + state_region<ROW, ROWP>(io.rows, 2, K) + soff);
             f4 acc[4][2];
             pg_zero(acc);
-            pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mL), lane, wave);
-            pg_wgrad(accL, bufB, bufA, wave, lane);
+            // the two waves of a SIMD share its matrix pipe: waves 4-7 take the two MFMA sections in the other order, so that one
+            // wave's LDS reads run under its partner's MFMAs
+            if (wave < 4) {
+                pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mL), lane, wave);
+                pg_wgrad(accL, bufB, bufA, wave, lane);
+            } else {
+                pg_wgrad(accL, bufB, bufA, wave, lane);
+                pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mL), lane, wave);
+            }
             __syncthreads();
             pg_write_d(bufB, acc, lane, wave);
         }
@@ -1065,8 +1072,15 @@ __global__ void __launch_bounds__(kPgThreads, 2) cemlp_pg_bwd_kernel(const DevCe
             if (live) pg_load_state(y2_st, io.saved + state_region<ROW, ROWP>(io.rows, 1, K) + soff);
             f4 acc[4][2];
             pg_zero(acc);
-            pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mR), lane, wave);
-            pg_wgrad(accR, bufB, bufA, wave, lane);
+            // the two waves of a SIMD share its matrix pipe: waves 4-7 take the two MFMA sections in the other order, so that one
+            // wave's LDS reads run under its partner's MFMAs
+            if (wave < 4) {
+                pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mR), lane, wave);
+                pg_wgrad(accR, bufB, bufA, wave, lane);
+            } else {
+                pg_wgrad(accR, bufB, bufA, wave, lane);
+                pg_mix_acc<NST>(acc, bufB, tabs + CF::ttoff(K, mR), lane, wave);
+            }
             __syncthreads();
             pg_write_d(bufB, acc, lane, wave);
         }
