@@ -21,6 +21,7 @@
 #include "pl_launch.hpp"
 #include "plw_launch.hpp"
 #include "pg_launch.hpp"
+#include "pq_launch.hpp"
 
 using namespace csmpn;
 
@@ -47,6 +48,7 @@ struct Switches {
     bool no_plw;         // CSMPN_NO_PLW=1      wide Cl(5,0) / Cl(4,1) layers leave the wide parity-lane kernels (cemlp_plw.hpp)
     bool plw8;           // CSMPN_PLW8=1        8 channels on the wide parity-lane kernels with one group
     bool no_pg;          // CSMPN_NO_PG=1       24 / 28 / 32-channel Cl(5,0) / Cl(4,1) layers leave the 16-row-tile MFMA-mixing kernels (cemlp_pg.hpp)
+    bool no_pq;          // CSMPN_NO_PQ=1       32-channel Cl(3,0) layers leave the 16-row-tile MFMA-mixing kernels (cemlp_pq.hpp) for the channel-MFMA ones
     bool no_share;       // CSMPN_NO_SHARE=1    general kernels: z does not alias the input tile
     bool no_phased;      // CSMPN_NO_PHASED=1   general kernels: backward of all blocks per tile instead of block by block
     bool no_sliced;      // CSMPN_NO_SLICED_GRADS=1  general kernels: parameter-gradient atomics onto one copy
@@ -72,7 +74,7 @@ const Switches& sw() {
         Switches r;
         r.no_cl = flag("CSMPN_NO_CL"); r.no_cm = flag("CSMPN_NO_CM"); r.no_cm_bwd = flag("CSMPN_NO_CM_BWD");
         r.no_pl = flag("CSMPN_NO_PL"); r.no_plw = flag("CSMPN_NO_PLW"); r.plw8 = flag("CSMPN_PLW8");
-        r.no_pg = flag("CSMPN_NO_PG");
+        r.no_pg = flag("CSMPN_NO_PG"); r.no_pq = flag("CSMPN_NO_PQ");
         r.no_share = flag("CSMPN_NO_SHARE"); r.no_phased = flag("CSMPN_NO_PHASED"); r.no_sliced = flag("CSMPN_NO_SLICED_GRADS");
         r.debug = getenv("CSMPN_DEBUG") != nullptr;
         r.force_ps = getenv("CSMPN_FORCE_PS") ? (atoi(getenv("CSMPN_FORCE_PS")) != 0) : -1;
@@ -641,6 +643,19 @@ unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of
 
 // bytes of the lane kernels' partial buffer (one slice of parameter-gradient sums per workgroup of a backward launch),
 // reserved at the END of the workspace; 0 when the shape is not served by those kernels
+// 16-row-tile MFMA-mixing kernels for Cl(3,0) (cemlp_pq.hpp): weight-fragment tables + one gradient slice per workgroup
+constexpr unsigned kPqGridCap = 768;   // three 4-wave workgroups per CU
+size_t pq_region_bytes(int ch, int i0) {
+    size_t best = 0;
+    for (int mode : {MODE_EDGE, MODE_NODE}) {
+        const int na = mode == MODE_EDGE ? i0 - ch : i0 - 2 * ch;
+        const size_t tf = cemlp_pq_table_floats_n3(mode, ch, na);
+        if (!tf) continue;
+        const size_t b = (tf + cemlp_pq_slice_floats_n3(mode, ch, na) * kPqGridCap) * sizeof(float) + 1024;
+        best = b > best ? b : best;
+    }
+    return best;
+}
 size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 3 || nblk < 1 || nblk > 2) return 0;
     const int ch = blocks[0].out_features;
@@ -657,7 +672,9 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     const size_t cmn = cemlp_cm_partial_floats_n3(MODE_NODE, nblk, ch, i0);
     cmf = cmn > cmf ? cmn : cmf;
     const size_t cm = cmf * sizeof(float) * kCmSliceCap;
-    return cm > cl ? cm : cl;
+    const size_t lane = cm > cl ? cm : cl;
+    const size_t pq = pq_region_bytes(ch, i0);   // the same region serves whichever family takes the launch
+    return pq > lane ? pq : lane;
 }
 // The channel-MFMA backward (cemlp_cmb.hpp, round 4: two waves per SIMD, tensors parked in LDS) serves the 16-channel
 // Cl(3,0) layers; CSMPN_NO_CM_BWD=1 leaves them to the row-per-lane backward (A/B measurements). Read ONCE per process: the
@@ -846,10 +863,66 @@ bool pg_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
     return true;
 }
 
+// CSMPN_FLAG_WEIGHTS_PACKED on an EGCL backward entry point: the workspace is the one the stage's forward used with the same
+// parameters - the weight-fragment tables of the 16-row-tile families (written by that forward's pack launch, both
+// directions) are still there and the backward does not pack again. Set around run_rows by those entry points.
+thread_local bool g_tables_ready = false;
+
+// 16-row-tile MFMA-mixing kernels for Cl(3,0) (cemlp_pq.hpp): two blocks of 32 channels, EGCL edge / node programs
+bool pq_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
+    if (sw().no_pq || sw().no_cm || id != ALG_N3) return false;
+    const DevCemlp& C = plan.C;
+    if (C.nblk != 2) return false;
+    const int ch = C.b[0].O;
+    if (ch != 32 || !C.b[0].w1_sub || C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub) return false;
+    int na = 0;
+    if (mode == MODE_EDGE) {
+        if (io.seg[0].ch != ch) return false;
+        na = io.nseg > 1 ? io.seg[1].ch : 0;
+        if (C.b[0].I != ch + na) return false;
+    } else if (mode == MODE_NODE) {
+        if (io.seg[0].ch != ch || io.seg[1].ch != ch) return false;
+        na = io.nseg > 2 ? io.seg[2].ch : 0;
+        if (C.b[0].I != 2 * ch + na) return false;
+    } else {
+        return false;
+    }
+    const size_t tf = cemlp_pq_table_floats_n3(mode, ch, na);
+    if (tf == 0 || !plan.workspace || plan.workspace_bytes < pq_region_bytes(ch, C.b[0].I)) return false;
+    // the backward runs on the state its forward saved (CSMPN_FLAG_SAVE_STATE, in ITS lane order); without the flag the
+    // forward still serves (it writes the row-major block-1 inputs) and the wave-pair backward (cemlp_cmp.hpp) recomputes
+    if (bwd && !(io.saved && io.save_state && cm_bwd_enabled())) return false;
+    *channels = ch;
+    *attr = na;
+    return true;
+}
+
 int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in, hipStream_t st, bool need_pack) {
     if (io_in.rows <= 0) return CSMPN_OK;
     RowIO io = io_in;
     io.stamps = g_stamps;
+    {
+        int channels = 0, attr = 0;
+        if (pq_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
+            const long tiles = (io.rows + 15) / 16;          // one 16-row tile per workgroup iteration, three 4-wave workgroups per CU
+            // backward: a workgroup ends with one slice of weight-gradient tiles (62-78 KB): at least two tiles each
+            const long want = bwd ? (tiles + 1) / 2 : tiles;
+            const unsigned grid = (unsigned)(want < (long)kPqGridCap ? (want > 0 ? want : 1) : kPqGridCap);
+            const size_t tb = cemlp_pq_table_floats_n3(mode, channels, attr) * sizeof(float);
+            float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
+            io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - cemlp_pq_slice_floats_n3(mode, channels, attr) * sizeof(float) * kPqGridCap);
+            if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // hand-over rows behind the saved block inputs
+            if (!cm_bwd_enabled()) io.save_state = 0;   // no state regions in the saved buffer (state_channels())
+            bool handled = false;
+            if (sw().debug) fprintf(stderr, "[csmpn] pq mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
+            HIP_TRY(launch_cemlp_pq_n3(mode, channels, attr, bwd, !(bwd && g_tables_ready), grid, st, plan.C, io, tabs, &handled));
+            if (handled) {
+                note_kernel("csmpn::cemlp_pq_%s_kernel<%s, ...> (mode %d, %d channels, %d attribute channels)", bwd ? "bwd" : "fwd",
+                            alg_name(id), mode, channels, attr);
+                return CSMPN_OK;
+            }
+        }
+    }
     {
         int channels = 0, attr = 0;
         if (pg_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
@@ -861,8 +934,9 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 32;   // hand-over rows behind the saved block inputs
             bool handled = false;
             if (sw().debug) fprintf(stderr, "[csmpn] pg mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
-            if (id == ALG_N5) HIP_TRY(launch_cemlp_pg_n5(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
-            else HIP_TRY(launch_cemlp_pg_n5m(mode, channels, attr, bwd, grid, st, plan.C, io, tabs, &handled));
+            const bool pack = !(bwd && g_tables_ready);
+            if (id == ALG_N5) HIP_TRY(launch_cemlp_pg_n5(mode, channels, attr, bwd, pack, grid, st, plan.C, io, tabs, &handled));
+            else HIP_TRY(launch_cemlp_pg_n5m(mode, channels, attr, bwd, pack, grid, st, plan.C, io, tabs, &handled));
             if (handled) {
                 note_kernel("csmpn::cemlp_pg_%s_kernel<%s, ...> (mode %d, %d channels, %d attribute channels)", bwd ? "bwd" : "fwd",
                             alg_name(id), mode, channels, attr);
@@ -1573,7 +1647,10 @@ int csmpn_egcl_edge_backward(const float* metric, int n, const csmpn_block_param
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // gh is then the [E, C, D] per-edge gradient table
     io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
     (void)N;
-    return run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream, need_pack);
+    g_tables_ready = (flags & CSMPN_FLAG_WEIGHTS_PACKED) != 0;
+    rc = run_rows(id, plan, MODE_EDGE, true, io, (hipStream_t)stream, need_pack);
+    g_tables_ready = false;
+    return rc;
 }
 
 static int node_io(const csmpn_block_params* blocks, int n_blocks, const float* h, int channels, const float* agg,
@@ -1637,7 +1714,10 @@ int csmpn_egcl_node_backward(const float* metric, int n, const csmpn_block_param
     io.resid_bwd = residual ? 1 : 0; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;
     io.save_state = (flags & CSMPN_FLAG_SAVE_STATE) ? 1 : 0;
-    return run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream, need_pack);
+    g_tables_ready = (flags & CSMPN_FLAG_WEIGHTS_PACKED) != 0;
+    rc = run_rows(id, plan, MODE_NODE, true, io, (hipStream_t)stream, need_pack);
+    g_tables_ready = false;
+    return rc;
 }
 
 }  // extern "C"

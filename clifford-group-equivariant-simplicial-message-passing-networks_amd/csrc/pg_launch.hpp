@@ -10,7 +10,7 @@ namespace csmpn {
     size_t cemlp_pg_table_floats_##tag(int mode, int channels, int attr);                                            \
     size_t cemlp_pg_slice_floats_##tag(int mode, int channels, int attr);                                            \
     bool has_cemlp_pg_##tag(int mode, int channels, int attr, bool bwd);                                            \
-    hipError_t launch_cemlp_pg_##tag(int mode, int channels, int attr, bool bwd, unsigned grid, hipStream_t st,      \
+    hipError_t launch_cemlp_pg_##tag(int mode, int channels, int attr, bool bwd, bool pack, unsigned grid, hipStream_t st,      \
                                      const DevCemlp& C, const RowIO& io, float* tabs, bool* handled);
 CSMPN_DECLARE_PG(n5)
 CSMPN_DECLARE_PG(n5m)

@@ -1,0 +1,13 @@
+// Host-visible launchers of the 16-row-tile MFMA-mixing kernels for Cl(3,0) at 32 channels (cemlp_pq.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cemlp_device.hpp"
+
+namespace csmpn {
+// floats of the weight-fragment tables / of one workgroup's gradient slice for (mode, channels, attribute channels); 0: shape not served
+size_t cemlp_pq_table_floats_n3(int mode, int channels, int attr);
+size_t cemlp_pq_slice_floats_n3(int mode, int channels, int attr);
+hipError_t launch_cemlp_pq_n3(int mode, int channels, int attr, bool bwd, bool pack, unsigned grid, hipStream_t st, const DevCemlp& C, const RowIO& io,
+                              float* tabs, bool* handled);
+}  // namespace csmpn

@@ -51,9 +51,12 @@ extern "C" {
 #define CSMPN_FLAG_NO_VALIDATE 2u    /* csmpn_csr_build, csmpn_embed_cemlp_*: skip the (synchronous) range check of the index table */
 #define CSMPN_FLAG_WEIGHTS_PACKED 1u /* forward entry points: the workspace already holds this
                                        CEMLP's packed weights (left there by an earlier forward with
-                                       the same parameters): skip the pack kernel. Accepted and
-                                       ignored by the backward entry points, which pack for their own
-                                       tile layout when it needs packed fragments at all. */
+                                       the same parameters): skip the pack kernel. csmpn_egcl_edge_backward /
+                                       csmpn_egcl_node_backward: the workspace is the one the stage's FORWARD
+                                       ran on, with the same parameters and untouched since - the 16-row-tile
+                                       kernel families (Cl(5,0) / Cl(4,1) at 24-32 channels, Cl(3,0) at 32) then
+                                       reuse the weight-fragment tables that forward packed; every other
+                                       backward packs for its own tile layout and ignores the flag. */
 
 #define CSMPN_FLAG_DETERMINISTIC 4u  /* csmpn_egcl_edge_forward/backward: no float atomics. The edge rows are
                                        not scattered: `agg` (forward) / `gh` (backward) is an [E, C, D] table in

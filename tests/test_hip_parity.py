@@ -399,9 +399,9 @@ def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
 
 
 def test_channel_mfma_backward_dispatched(pkg):
-    """Round 4: the channel-MFMA backward (cemlp_cmb.hpp: 16 channels, two waves per SIMD; cemlp_cmp.hpp: 32 channels, wave
-    pairs) is the default of those widths: the shape cases again in a child process with the dispatch log on - the log must
-    show that kernel family taking both backward stages."""
+    """The lane-kernel backward of the Cl(3,0) 16- and 32-channel widths (round 4: cemlp_cmb.hpp, 16 channels, two waves per SIMD;
+    round 5: cemlp_pq.hpp, 32 channels, 16-row tiles with three workgroups per CU) is the default of those widths: the shape
+    cases again in a child process with the dispatch log on - the log must show that kernel family taking both backward stages."""
     import subprocess
     env = dict(os.environ, CSMPN_DEBUG="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-s", "-m", "gpu", "-x", "-k",
@@ -411,9 +411,9 @@ def test_channel_mfma_backward_dispatched(pkg):
     tail = r.stderr[:1500] + "\n...\n" + (r.stdout + r.stderr)[-2500:]
     assert r.returncode == 0, tail
     log = r.stdout + r.stderr
-    for ch in (16, 32):
-        assert f"cm mode=1 bwd=1 channels={ch}" in log and f"cm mode=2 bwd=1 channels={ch}" in log, \
-            f"the channel-MFMA backward was not dispatched for {ch} channels\n" + tail
+    for fam, ch in (("cm", 16), ("pq", 32)):
+        assert f"{fam} mode=1 bwd=1 channels={ch}" in log and f"{fam} mode=2 bwd=1 channels={ch}" in log, \
+            f"the {fam} backward was not dispatched for {ch} channels\n" + tail
     assert " passed" in log and "failed" not in log, tail
 
 
@@ -435,47 +435,50 @@ torch.save([g.cpu() for g in gs], sys.argv[2])
 """
 
 
-@pytest.mark.parametrize("C", [16, 32])
-def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path, C):
-    """The channel-MFMA backward where every wave walks several row tiles with dynamic tile claims (40 000 edges = 2 500
-    tiles; 3 000 nodes): d/dh and every parameter gradient against the general row-tile kernels of the same layer
-    (CSMPN_NO_CM=1), each in its own process (the switches are read once per process)."""
+@pytest.mark.parametrize("C,fam,extra_env", [(16, "cm", {}), (32, "pq", {}), (32, "cm", {"CSMPN_NO_PQ": "1"})],
+                         ids=["16", "32", "32-wave-pairs"])
+def test_channel_mfma_backward_many_tiles_per_wave(pkg, tmp_path, C, fam, extra_env):
+    """The lane-kernel backward where every wave / workgroup walks several row tiles (40 000 edges = 2 500 tiles; 3 000 nodes;
+    16 channels: dynamic tile claims): d/dh and every parameter gradient against the general row-tile kernels of the same
+    layer (CSMPN_NO_CM=1), each in its own process (the switches are read once per process). 32 channels: the 16-row-tile
+    family of round 5 (cemlp_pq.hpp) and, under CSMPN_NO_PQ=1, the wave-pair backward of round 4 (cemlp_cmp.hpp)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     script = _CM_BWD_SCRIPT.replace("C, N, E = (1.0, 1.0, 1.0), 16,", f"C, N, E = (1.0, 1.0, 1.0), {C},")
     assert f"{C}, 3000, 40000" in script
-    for tag, extra in (("general", {"CSMPN_NO_CM": "1", "CSMPN_DEBUG": "1"}), ("cm", {"CSMPN_DEBUG": "1"})):
+    for tag, extra in (("general", {"CSMPN_NO_CM": "1", "CSMPN_DEBUG": "1"}), ("cm", dict(extra_env, CSMPN_DEBUG="1"))):
         f = str(tmp_path / f"g_{tag}.pt")
         r = subprocess.run([sys.executable, "-c", script, root, f], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-3000:]
         if tag == "cm":
-            assert "cm mode=1 bwd=1" in r.stderr and "cm mode=2 bwd=1" in r.stderr, r.stderr[-2000:]
+            assert f"{fam} mode=1 bwd=1" in r.stderr and f"{fam} mode=2 bwd=1" in r.stderr, r.stderr[-2000:]
         else:
-            assert "cm mode=" not in r.stderr, r.stderr[-2000:]
+            assert "cm mode=" not in r.stderr and "pq mode=" not in r.stderr, r.stderr[-2000:]
         outs[tag] = torch.load(f)
     for i, (a, b) in enumerate(zip(outs["cm"], outs["general"])):
         err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
         assert err < 2e-5, (i, err)
 
 
-def test_channel_mfma_forward_without_its_backward(pkg, tmp_path):
-    """CSMPN_NO_CM_BWD=1 (the documented A/B switch) on the 32-channel width: the channel-MFMA FORWARD still runs, its
-    pair backward does not, and the saved buffer is then sized WITHOUT state regions - the forward must not write any
-    (round-4 advice: it stored y / R / s ~6 KB per row past the end of the allocation). Same gradients as the default
-    path; the log shows the forward family and no channel-MFMA backward."""
+@pytest.mark.parametrize("fam,extra_env", [("pq", {}), ("cm", {"CSMPN_NO_PQ": "1"})], ids=["16-row-tiles", "channel-mfma"])
+def test_channel_mfma_forward_without_its_backward(pkg, tmp_path, fam, extra_env):
+    """CSMPN_NO_CM_BWD=1 (the documented A/B switch) on the 32-channel width: the lane-kernel FORWARD still runs (the 16-row-tile
+    family; the channel-MFMA one under CSMPN_NO_PQ=1), its backward does not, and the saved buffer is then sized WITHOUT
+    state regions - the forward must not write any (round-4 advice: it stored y / R / s ~6 KB per row past the end of the
+    allocation). Same gradients as the default path; the log shows the forward family and no lane-kernel backward."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = _CM_BWD_SCRIPT.replace("C, N, E = (1.0, 1.0, 1.0), 16,", "C, N, E = (1.0, 1.0, 1.0), 32,")
     outs = {}
-    for tag, extra in (("nobwd", {"CSMPN_NO_CM_BWD": "1", "CSMPN_DEBUG": "1"}), ("cm", {"CSMPN_DEBUG": "1"})):
+    for tag, extra in (("nobwd", dict(extra_env, CSMPN_NO_CM_BWD="1", CSMPN_DEBUG="1")), ("cm", dict(extra_env, CSMPN_DEBUG="1"))):
         f = str(tmp_path / f"g_{tag}.pt")
         r = subprocess.run([sys.executable, "-c", script, root, f], env=dict(os.environ, **extra), capture_output=True,
                            text=True, timeout=600, cwd=root)
         assert r.returncode == 0, r.stderr[-3000:]
-        assert "cm mode=1 bwd=0" in r.stderr and "cm mode=2 bwd=0" in r.stderr, r.stderr[-2000:]
-        assert ("cm mode=1 bwd=1" in r.stderr) == (tag == "cm"), r.stderr[-2000:]
+        assert f"{fam} mode=1 bwd=0" in r.stderr and f"{fam} mode=2 bwd=0" in r.stderr, r.stderr[-2000:]
+        assert (f"{fam} mode=1 bwd=1" in r.stderr) == (tag == "cm"), r.stderr[-2000:]
         outs[tag] = torch.load(f)
     for i, (a, b) in enumerate(zip(outs["nobwd"], outs["cm"])):
         err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
@@ -484,12 +487,14 @@ def test_channel_mfma_forward_without_its_backward(pkg, tmp_path):
 
 @pytest.mark.parametrize("metric,C,N,E,aggr,family", [
     ((1.0, 1.0, 1.0), 8, 700, 30001, "mean", "cemlp_cl_bwd_kernel"),          # S1's kernels: s per block
-    ((1.0, 1.0, 1.0), 32, 500, 9001, "sum", "cemlp_cmp_kernel"),              # md17's width: y, R, s per block
+    # md17's width: y, R, s per block - with the state the 16-row-tile kernels (cemlp_pq.hpp), without it their forward + the
+    # wave-pair backward (cemlp_cmp.hpp) that recomputes from the saved block inputs
+    ((1.0, 1.0, 1.0), 32, 500, 9001, "sum", "cemlp_pq_bwd_kernel|cemlp_cmp_kernel"),
     ((1.0, 1.0, 1.0, 1.0, -1.0), 8, 300, 5001, "mean", "cemlp_pl_kernel"),    # S3's kernels: y, R, s per block, lane order
     # the convex-hulls width: with the state the 16-row-tile kernels (cemlp_pg.hpp: forward AND backward), without it their
     # forward + the wide parity-lane backward that recomputes from the saved block inputs
     ((1.0, 1.0, 1.0, 1.0, 1.0), 28, 200, 2001, "mean", "cemlp_pg_bwd_kernel|cemlp_plw_bwd_kernel"),
-], ids=["cl8", "cmp32", "pl8", "pg28"])
+], ids=["cl8", "pq32", "pl8", "pg28"])
 def test_save_state_matches_recompute(pkg, monkeypatch, metric, C, N, E, aggr, family):
     """CSMPN_FLAG_SAVE_STATE (round 4): the stage forwards also store per block what the backward would recompute - s (the
     block's output in front of its layer norm) on the Cl(3,0) 8-channel kernels; y, R and s on the 32-channel and the D = 32

@@ -12,7 +12,7 @@ def main():
     C = int(os.environ.get("PG_C", "28"))
     N = int(os.environ.get("PG_N", "37"))
     E = int(os.environ.get("PG_E", "203"))
-    metric = (1.0,) * 5 if os.environ.get("PG_M", "0") == "0" else (1.0, 1.0, 1.0, 1.0, -1.0)
+    metric = {"0": (1.0,) * 5, "1": (1.0, 1.0, 1.0, 1.0, -1.0), "3": (1.0, 1.0, 1.0)}[os.environ.get("PG_M", "0")]   # 3: Cl(3,0) (cemlp_pq.hpp)
     aggr = os.environ.get("PG_AGGR", "mean")
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
@@ -23,7 +23,7 @@ def main():
     sd = layer.state_dict(); sd.update(p); layer.load_state_dict(sd, strict=True)
     layer = layer.to(dev)
     h, ei, ea, na = O.synthetic_complex(o, N, E, C, seed=5)
-    gout = torch.randn(N, C, 32, generator=gen)
+    gout = torch.randn(N, C, 1 << len(metric), generator=gen)
     hd = h.to(dev).requires_grad_(True)
     y = layer(hd, ei.to(dev), ea.to(dev), na.to(dev))
     (y * gout.to(dev)).sum().backward()
