@@ -905,8 +905,9 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
         int channels = 0, attr = 0;
         if (pq_eligible(id, plan, mode, bwd, io, &channels, &attr)) {
             const long tiles = (io.rows + 15) / 16;          // one 16-row tile per workgroup iteration, three 4-wave workgroups per CU
-            // backward: a workgroup ends with one slice of weight-gradient tiles (62-78 KB): at least two tiles each
-            const long want = bwd ? (tiles + 1) / 2 : tiles;
+            // (backward: a workgroup ends with one slice of weight-gradient tiles, 62-78 KB; measured with 1 / 2 / 3 tiles per
+            // workgroup on launches below the cap: md17 step 2.11 / 2.28 / 2.43 ms, M32 1.024 / 1.008 / 1.012e8 edges/s: one tile)
+            const long want = tiles;
             const unsigned grid = (unsigned)(want < (long)kPqGridCap ? (want > 0 ? want : 1) : kPqGridCap);
             const size_t tb = cemlp_pq_table_floats_n3(mode, channels, attr) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
