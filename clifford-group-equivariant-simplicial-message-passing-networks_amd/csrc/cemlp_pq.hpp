@@ -204,6 +204,10 @@ CSMPN_DEV void pq_load_state(float (&t)[8], const float* p) {
     const f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + 256));
     t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w; t[4] = b.x; t[5] = b.y; t[6] = b.z; t[7] = b.w;
 }
+// piece i of thread t of a C-channel row tile: 64 pieces per row - the row (t >> 6) + 4 i is the same for a whole wave (a scalar),
+// the piece is the lane; index-array entries of such a row are scalars too (row pointers in SGPRs, scalar validity branches)
+CSMPN_DEV int pq_row_of(int t, int i) { return __builtin_amdgcn_readfirstlane(t >> 6) + 4 * i; }
+CSMPN_DEV int pq_sidx(const int* a, int k) { return __builtin_amdgcn_readfirstlane(a[k]); }
 // sum over the four lanes n, n + 16, n + 32, n + 48 of a wave (the four channel groups of a row)
 CSMPN_DEV float pq_sum_q(float v) {
     v += __shfl_xor(v, 16);
@@ -263,7 +267,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     int* sidx_n = sidx + 64;                                          // [48..63] node program: 1 / max(deg, 1) (float); the next tile's in the other half
     constexpr int PPR = C * 2, PPA = 4 * CF::NSTA * 2;                // 16-byte pieces per row: a C-channel segment, the attribute chunk padded to whole k-steps
     constexpr int NPRE = PPR * kPqRows / kPqThreads, NPA = (PPA * kPqRows + kPqThreads - 1) / kPqThreads;
-    static_assert(NPRE * kPqThreads == PPR * kPqRows, "whole pieces per thread");
+    static_assert(NPRE * kPqThreads == PPR * kPqRows && PPR == 64, "whole pieces per thread, one row per wave and piece index (pq_row_of)");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = tid & 15, cq = tid >> 4;                            // ROW layout: channels cq, cq + 16
     const int mp = wave & 1, mot = wave >> 1;                         // MIX layout: piece, output tile
@@ -312,12 +316,12 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         const float* sc_ = reinterpret_cast<const float*>(idx) + 48;
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
-            const int p = t + i * kPqThreads, rr = p / PPR, e = p % PPR;
+            const int rr = pq_row_of(t, i), e = t & 63;
             pre_a[i] = pre_b[i] = f4{0.f, 0.f, 0.f, 0.f};
-            if (idx[rr] >= 0) {
+            if (pq_sidx(idx, rr) >= 0) {
                 if constexpr (MODE == MODE_EDGE) {
-                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)idx[rr] * ROW + 4 * e);
-                    pre_b[i] = pg_ld4(io.seg[0].b + (size_t)idx[16 + rr] * ROW + 4 * e);
+                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)pq_sidx(idx, rr) * ROW + 4 * e);
+                    pre_b[i] = pg_ld4(io.seg[0].b + (size_t)pq_sidx(idx, 16 + rr) * ROW + 4 * e);
                 } else {
                     pre_a[i] = pg_ld4(io.seg[0].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e);
                     pre_b[i] = pg_ld4(io.seg[1].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e) * sc_[rr];
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         {
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 if constexpr (MODE == MODE_EDGE) {
                     pg_st4(bufA + pq_off(e >> 1, rr, e & 1), pre_a[i] - pre_b[i]);
                 } else {
@@ -398,7 +402,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                     if (io.save) {
 #pragma unroll
                         for (int i = 0; i < NPRE; ++i) {
-                            const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                            const int rr = pq_row_of(tid, i), e = tid & 63;
                             if (row0 + rr < io.rows) pg_st4(io.save + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufB + pq_off(e >> 1, rr, e & 1)));
                         }
                     }
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
             if (io.row_store) {   // deterministic mode: message rows to the [E, C, D] table in sorted edge order
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) {
-                    const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                    const int rr = pq_row_of(tid, i), e = tid & 63;
                     if (row0 + rr < io.rows) pg_st4(io.agg + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufA + pq_off(e >> 1, rr, e & 1)));
                 }
             } else {
@@ -530,10 +534,10 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 static_assert(ROW == kPqThreads, "one column per thread");
                 const int ch = tid >> 3, d = tid & 7;
                 float acc = 0.f;
-                int cur = sidx[0];
+                int cur = pq_sidx(sidx, 0);
 #pragma unroll
                 for (int rr = 0; rr < kPqRows; ++rr) {
-                    const int t_ = sidx[rr];
+                    const int t_ = pq_sidx(sidx, rr);
                     if (t_ != cur) {
                         if (cur >= 0) atomicAdd(io.agg + (size_t)cur * ROW + tid, acc);
                         cur = t_;
@@ -546,7 +550,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         } else {
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 if (row0 + rr < io.rows) {
                     f4 v = pg_ld4(bufA + pq_off(e >> 1, rr, e & 1));
                     if (io.resid) v += pg_ld4(io.resid + (size_t)(row0 + rr) * ROW + 4 * e);
@@ -713,7 +717,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
     int* sidx = reinterpret_cast<int*>(smem + CF::b_idx);
     int* sidx_n = sidx + 64;
     constexpr int NPRE = PPR * kPqRows / kPqThreads;               // 16-byte pieces of a C-channel tile per thread
-    static_assert(NPRE * kPqThreads == PPR * kPqRows, "whole pieces per thread");
+    static_assert(NPRE * kPqThreads == PPR * kPqRows && PPR == 64, "whole pieces per thread, one row per wave and piece index (pq_row_of)");
     const f4* tabs = reinterpret_cast<const f4*>(io.plw_tabs);
     PgStamp stamp(0);
     {
@@ -757,9 +761,9 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
     auto issue_gout = [&](const int* idx, long tile_, int t) {
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
-            const int p = t + i * kPqThreads, rr = p / PPR, e = p % PPR;
+            const int rr = pq_row_of(t, i), e = t & 63;
             pre[i] = f4{0.f, 0.f, 0.f, 0.f};
-            if (idx[rr] >= 0) {
+            if (pq_sidx(idx, rr) >= 0) {
                 if constexpr (K == 1) {
                     const size_t grow = MODE == MODE_EDGE ? (size_t)idx[rr] : (size_t)(tile_ * kPqRows + rr);
                     pre[i] = pg_ld4(io.gy + grow * ROW + 4 * e);
@@ -792,7 +796,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             // ---- d/d(block output) rows (requested during the previous tile) -> A
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 pg_st4(bufA + pq_off(e >> 1, rr, e & 1), pre[i]);
             }
             if (tid < kPqRows) load_idx(sidx_n, tile + gridDim.x, tid);
@@ -978,14 +982,14 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);     // W1^T: in front of the gathers
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 xa[i] = f4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (K == 0 && MODE == MODE_EDGE) xb[i] = f4{0.f, 0.f, 0.f, 0.f};
-                if (sidx[rr] >= 0) {
+                if (pq_sidx(sidx, rr) >= 0) {
                     if constexpr (K == 1) xa[i] = pg_ld4(io.saved + (size_t)(row0 + rr) * ROW + 4 * e);
                     else if constexpr (MODE == MODE_EDGE) {
-                        xa[i] = pg_ld4(io.seg[0].a + (size_t)sidx[rr] * ROW + 4 * e);
-                        xb[i] = pg_ld4(io.seg[0].b + (size_t)sidx[16 + rr] * ROW + 4 * e);
+                        xa[i] = pg_ld4(io.seg[0].a + (size_t)pq_sidx(sidx, rr) * ROW + 4 * e);
+                        xb[i] = pg_ld4(io.seg[0].b + (size_t)pq_sidx(sidx, 16 + rr) * ROW + 4 * e);
                     } else xa[i] = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
                 }
             }
@@ -1049,7 +1053,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             });
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 if constexpr (K == 0 && MODE == MODE_EDGE) xa[i] -= xb[i];
                 pg_st4(bufA + pq_off(e >> 1, rr, e & 1), xa[i]);
             }
@@ -1093,9 +1097,9 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             __syncthreads();             // every wave is done with h in A
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
-                const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                const int rr = pq_row_of(tid, i), e = tid & 63;
                 f4 v = f4{0.f, 0.f, 0.f, 0.f};
-                if (sidx[rr] >= 0) v = pg_ld4(io.seg[1].a + (size_t)(row0 + rr) * ROW + 4 * e) * sscale[rr];
+                if (pq_sidx(sidx, rr) >= 0) v = pg_ld4(io.seg[1].a + (size_t)(row0 + rr) * ROW + 4 * e) * sscale[rr];
                 pg_st4(bufA + pq_off(e >> 1, rr, e & 1), v);
             }
             __syncthreads();
@@ -1116,7 +1120,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             if constexpr (K == 1) {
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) {
-                    const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                    const int rr = pq_row_of(tid, i), e = tid & 63;
                     if (row0 + rr < io.rows) pg_st4(io.plw_g1 + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufB + pq_off(e >> 1, rr, e & 1)));
                 }
             } else if constexpr (MODE == MODE_EDGE) {
@@ -1124,17 +1128,17 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                     if (io.row_store) {
 #pragma unroll
                         for (int i = 0; i < NPRE; ++i) {
-                            const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                            const int rr = pq_row_of(tid, i), e = tid & 63;
                             if (row0 + rr < io.rows) pg_st4(io.gx[0] + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufB + pq_off(e >> 1, rr, e & 1)));
                         }
                     } else {
                         static_assert(ROW == kPqThreads, "one column per thread");
                         const int ch = tid >> 3, d = tid & 7;
                         float acc = 0.f;
-                        int cur = sidx[0];
+                        int cur = pq_sidx(sidx, 0);
 #pragma unroll
                         for (int rr = 0; rr < kPqRows; ++rr) {
-                            const int t_ = sidx[rr];
+                            const int t_ = pq_sidx(sidx, rr);
                             if (t_ != cur) {
                                 if (cur >= 0) atomicAdd(io.gx[0] + (size_t)cur * ROW + tid, acc);
                                 cur = t_;
@@ -1142,7 +1146,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                             }
                             const float v = bufB[pq_off(ch, rr, d >> 2) + (d & 3)];
                             acc += v;
-                            if (t_ >= 0) atomicAdd(io.gx[0] + (size_t)sidx[16 + rr] * ROW + tid, -v);
+                            if (t_ >= 0) atomicAdd(io.gx[0] + (size_t)pq_sidx(sidx, 16 + rr) * ROW + tid, -v);
                         }
                         if (cur >= 0) atomicAdd(io.gx[0] + (size_t)cur * ROW + tid, acc);
                     }
@@ -1155,7 +1159,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             } else {
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) {
-                    const int p = tid + i * kPqThreads, rr = p / PPR, e = p % PPR;
+                    const int rr = pq_row_of(tid, i), e = tid & 63;
                     if (row0 + rr < io.rows) {
                         if (io.gx[0]) {
                             f4 v = pg_ld4(bufA + pq_off(e >> 1, rr, e & 1));
