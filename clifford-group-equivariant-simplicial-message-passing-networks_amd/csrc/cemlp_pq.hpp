@@ -314,14 +314,27 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     f4 pre_a[NPRE], pre_b[NPRE], pre_x[NPA];
     auto issue_rows = [&](const int* idx, long tile_, int t) {
         const float* sc_ = reinterpret_cast<const float*>(idx) + 48;
+        // the index reads of all rows first (one LDS round trip), then the scalar row pointers and the loads
+        int ia[NPRE], ib[NPRE];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int rr = pq_row_of(t, i);
+            ia[i] = idx[rr];
+            ib[i] = MODE == MODE_EDGE ? idx[16 + rr] : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            ia[i] = __builtin_amdgcn_readfirstlane(ia[i]);
+            ib[i] = __builtin_amdgcn_readfirstlane(ib[i]);
+        }
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int rr = pq_row_of(t, i), e = t & 63;
             pre_a[i] = pre_b[i] = f4{0.f, 0.f, 0.f, 0.f};
-            if (pq_sidx(idx, rr) >= 0) {
+            if (ia[i] >= 0) {
                 if constexpr (MODE == MODE_EDGE) {
-                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)pq_sidx(idx, rr) * ROW + 4 * e);
-                    pre_b[i] = pg_ld4(io.seg[0].b + (size_t)pq_sidx(idx, 16 + rr) * ROW + 4 * e);
+                    pre_a[i] = pg_ld4(io.seg[0].a + (size_t)ia[i] * ROW + 4 * e);
+                    pre_b[i] = pg_ld4(io.seg[0].b + (size_t)ib[i] * ROW + 4 * e);
                 } else {
                     pre_a[i] = pg_ld4(io.seg[0].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e);
                     pre_b[i] = pg_ld4(io.seg[1].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e) * sc_[rr];
@@ -534,10 +547,15 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 static_assert(ROW == kPqThreads, "one column per thread");
                 const int ch = tid >> 3, d = tid & 7;
                 float acc = 0.f;
-                int cur = pq_sidx(sidx, 0);
+                int tg[kPqRows];
+#pragma unroll
+                for (int rr = 0; rr < kPqRows; ++rr) tg[rr] = sidx[rr];
+#pragma unroll
+                for (int rr = 0; rr < kPqRows; ++rr) tg[rr] = __builtin_amdgcn_readfirstlane(tg[rr]);
+                int cur = tg[0];
 #pragma unroll
                 for (int rr = 0; rr < kPqRows; ++rr) {
-                    const int t_ = pq_sidx(sidx, rr);
+                    const int t_ = tg[rr];
                     if (t_ != cur) {
                         if (cur >= 0) atomicAdd(io.agg + (size_t)cur * ROW + tid, acc);
                         cur = t_;
@@ -759,13 +777,18 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
     };
     f4 pre[NPRE];
     auto issue_gout = [&](const int* idx, long tile_, int t) {
+        int ia[NPRE];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) ia[i] = idx[pq_row_of(t, i)];
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) ia[i] = __builtin_amdgcn_readfirstlane(ia[i]);
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int rr = pq_row_of(t, i), e = t & 63;
             pre[i] = f4{0.f, 0.f, 0.f, 0.f};
-            if (pq_sidx(idx, rr) >= 0) {
+            if (ia[i] >= 0) {
                 if constexpr (K == 1) {
-                    const size_t grow = MODE == MODE_EDGE ? (size_t)idx[rr] : (size_t)(tile_ * kPqRows + rr);
+                    const size_t grow = MODE == MODE_EDGE ? (size_t)ia[i] : (size_t)(tile_ * kPqRows + rr);
                     pre[i] = pg_ld4(io.gy + grow * ROW + 4 * e);
                 } else {
                     pre[i] = pg_ld4(io.plw_g1 + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e);
@@ -980,16 +1003,28 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         {
             PQ_PHASE_IDS();
             pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);     // W1^T: in front of the gathers
+            int ia[NPRE], ib[NPRE];
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                const int rr = pq_row_of(tid, i);
+                ia[i] = sidx[rr];
+                ib[i] = (K == 0 && MODE == MODE_EDGE) ? sidx[16 + rr] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < NPRE; ++i) {
+                ia[i] = __builtin_amdgcn_readfirstlane(ia[i]);
+                ib[i] = __builtin_amdgcn_readfirstlane(ib[i]);
+            }
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
                 const int rr = pq_row_of(tid, i), e = tid & 63;
                 xa[i] = f4{0.f, 0.f, 0.f, 0.f};
                 if constexpr (K == 0 && MODE == MODE_EDGE) xb[i] = f4{0.f, 0.f, 0.f, 0.f};
-                if (pq_sidx(sidx, rr) >= 0) {
+                if (ia[i] >= 0) {
                     if constexpr (K == 1) xa[i] = pg_ld4(io.saved + (size_t)(row0 + rr) * ROW + 4 * e);
                     else if constexpr (MODE == MODE_EDGE) {
-                        xa[i] = pg_ld4(io.seg[0].a + (size_t)pq_sidx(sidx, rr) * ROW + 4 * e);
-                        xb[i] = pg_ld4(io.seg[0].b + (size_t)pq_sidx(sidx, 16 + rr) * ROW + 4 * e);
+                        xa[i] = pg_ld4(io.seg[0].a + (size_t)ia[i] * ROW + 4 * e);
+                        xb[i] = pg_ld4(io.seg[0].b + (size_t)ib[i] * ROW + 4 * e);
                     } else xa[i] = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
                 }
             }
@@ -1135,10 +1170,15 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                         static_assert(ROW == kPqThreads, "one column per thread");
                         const int ch = tid >> 3, d = tid & 7;
                         float acc = 0.f;
-                        int cur = pq_sidx(sidx, 0);
+                        int tg[kPqRows], ts[kPqRows];
+#pragma unroll
+                        for (int rr = 0; rr < kPqRows; ++rr) { tg[rr] = sidx[rr]; ts[rr] = sidx[16 + rr]; }
+#pragma unroll
+                        for (int rr = 0; rr < kPqRows; ++rr) { tg[rr] = __builtin_amdgcn_readfirstlane(tg[rr]); ts[rr] = __builtin_amdgcn_readfirstlane(ts[rr]); }
+                        int cur = tg[0];
 #pragma unroll
                         for (int rr = 0; rr < kPqRows; ++rr) {
-                            const int t_ = pq_sidx(sidx, rr);
+                            const int t_ = tg[rr];
                             if (t_ != cur) {
                                 if (cur >= 0) atomicAdd(io.gx[0] + (size_t)cur * ROW + tid, acc);
                                 cur = t_;
@@ -1146,7 +1186,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                             }
                             const float v = bufB[pq_off(ch, rr, d >> 2) + (d & 3)];
                             acc += v;
-                            if (t_ >= 0) atomicAdd(io.gx[0] + (size_t)pq_sidx(sidx, 16 + rr) * ROW + tid, -v);
+                            if (t_ >= 0) atomicAdd(io.gx[0] + (size_t)ts[rr] * ROW + tid, -v);
                         }
                         if (cur >= 0) atomicAdd(io.gx[0] + (size_t)cur * ROW + tid, acc);
                     }
