@@ -712,17 +712,97 @@ CSMPN_DEV void pq_store_unit(float* base, const f4 (&acc)[4], int ot, int ct, in
     const bool live = row0 + r < io.rows;                                                                           \
     (void)l16; (void)live; (void)r; (void)cq; (void)mp; (void)mot; (void)lane
 
+// grads += sum over the workgroups' slices, fixed order (as pg_reduce_kernel: 64 elements per workgroup, four slice groups, compensated)
+template <class ALG, class CF, int K>
+CSMPN_DEV void pq_reduce_body(const DevCemlp& Cd, const float* part, int nslices, int block) {
+    constexpr int C = CF::C, G = CF::G, P = CF::P, SF = CF::slice_floats(K), SW = CF::slice_w(K);
+    __shared__ float red[4][64];
+    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int e = block * 64 + j;
+    float s = 0.f, comp = 0.f;
+    auto add = [&](float v) {
+        const float yk = v - comp, t = s + yk;
+        comp = (t - s) - yk;
+        s = t;
+    };
+    if (e < SF) {
+        for (int sl = q; sl < nslices; sl += 64) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = sl + 4 * i < nslices ? part[(size_t)(sl + 4 * i) * SF + e] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) add(v[i]);
+        }
+    }
+    red[q][j] = s;
+    __syncthreads();
+    if (q != 0 || e >= SF) return;
+    s = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+    const DevBlock& B = Cd.b[K];
+    if (e < SW) {
+        int m = 0, f = e;
+        bool found = false;
+        static_for<0, CF::nmat(K)>([&](auto mm) {
+            constexpr int m_ = decltype(mm)::value;
+            if (!found && e >= CF::woff(K, m_) && e < CF::woff(K, m_) + CF::wmat_floats(K, m_)) { m = m_; f = e - CF::woff(K, m_); found = true; }
+        });
+        const int nct = CF::nct(K, m), which = CF::which(K, m);
+        const int v = f & 3, lane = (f >> 2) & 63;
+        int rest = f >> 8;
+        const int ct = rest % nct; rest /= nct;
+        const int ot = rest & 1, g = rest >> 1;
+        const int o = 16 * ot + 4 * (lane >> 4) + v, cl = 16 * ct + (lane & 15);
+        if (o < C && cl < CF::nch(K, m)) {
+            float* gW = which == 0 ? B.gW1 : (which == 1 ? B.gWR : B.gWL);
+            const int I = which == 0 ? B.I : C;
+            gW[((size_t)o * I + CF::cbase(K, m) + cl) * G + g] += s;
+        }
+    } else {
+        const int f = e - SW, ch = f / CF::kSmall, idx = f % CF::kSmall;
+        if (ch < C) {
+            if (idx < P) B.gw[ch * P + idx] += s;
+            else if (idx < P + G) B.gan[ch * G + (idx - P)] += s;
+            else if (idx >= CF::s_gate && idx < CF::s_gate + 2 * G) { const int g = (idx - CF::s_gate) >> 1; if (idx & 1) B.gsb[ch * G + g] += s; else B.gsa[ch * G + g] += s; }
+            else if (idx == CF::s_b1) { if (B.has_b1) B.gb1[ch] += s; }
+            else if (idx == CF::s_la) B.gla[ch] += s;
+            else if (idx == CF::s_bL) B.gbL[ch] += s;
+        }
+    }
+}
+template <class ALG, class CF, int K>
+__global__ void __launch_bounds__(256) pq_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
+    pq_reduce_body<ALG, CF, K>(Cd, part, nslices, blockIdx.x);
+}
+
+// Block 1's slices are summed by EXTRA workgroups of the block-0 launch (the first gridDim - aux.groups: the block-1 launch has finished -
+// stream order - and its slices live in their own region): the memory-bound sums run under the block-0 tiles instead of in a
+// launch of their own between the two (md17-sized launches: 15 us per edge stage).
+struct PqAux {
+    const float* part1;   // block 1's slices
+    int groups;           // workgroups of this launch that run tiles
+    int nslices1;         // slices behind part1
+};
 #ifndef PQ_BWD_WPE
 #define PQ_BWD_WPE 3      // waves per SIMD the backward is compiled for (3: 168 registers; 2: 256)
 #endif
 template <class ALG, class CF, int K>
-__global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg) {
+__global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(const DevCemlp C_arg, const RowIO io_arg, const PqAux aux) {
     typedef const char __attribute__((address_space(4))) * KArgPtr;
     const KArgPtr ka = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr size_t kIoOffset = (sizeof(DevCemlp) + alignof(RowIO) - 1) / alignof(RowIO) * alignof(RowIO);
     const DevCemlp& Cd = *(const DevCemlp*)(const char*)ka;
     const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
     (void)C_arg; (void)io_arg;
+    // (the summing workgroups come FIRST in the grid: dispatched in index order, they start with the launch)
+    const int nred = (int)gridDim.x - aux.groups;
+    if constexpr (K == 0) {
+        if ((int)blockIdx.x < nred) {
+            pq_reduce_body<ALG, CF, 1>(Cd, aux.part1, aux.nslices1, (int)blockIdx.x);
+            return;
+        }
+    }
+    const int ngroups = aux.groups;                 // workgroups that walk the tiles
+    const int group = (int)blockIdx.x - nred;       // ... and this one's index among them
     constexpr int C = CF::C, MODE = CF::MODE, NA = CF::NA, D = 8, G = 4, P = CF::P, ROW = CF::ROW, NST = CF::NST;
     constexpr int PPR = C * 2;
     constexpr int NM = CF::nmat(K), mR = NM - 2, mL = NM - 1;
@@ -796,12 +876,12 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             }
         }
     };
-    if (threadIdx.x < kPqRows) load_idx(sidx, blockIdx.x, threadIdx.x);
+    if (threadIdx.x < kPqRows) load_idx(sidx, group, threadIdx.x);
     __syncthreads();
-    issue_gout(sidx, blockIdx.x, threadIdx.x);
+    issue_gout(sidx, group, threadIdx.x);
     stamp(0);
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = group; tile < ntiles; tile += ngroups) {
         const long row0 = tile * kPqRows;
         const float* const sscale = reinterpret_cast<const float*>(sidx) + 48;
         float s_st[2][8], y_st[2][8];     // state rows of the first ROW phase, requested in front of the staging barrier
@@ -822,7 +902,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                 const int rr = pq_row_of(tid, i), e = tid & 63;
                 pg_st4(bufA + pq_off(e >> 1, rr, e & 1), pre[i]);
             }
-            if (tid < kPqRows) load_idx(sidx_n, tile + gridDim.x, tid);
+            if (tid < kPqRows) load_idx(sidx_n, tile + ngroups, tid);
         }
         __syncthreads();
         stamp(1);
@@ -1151,7 +1231,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         // ---- rows out; the next tile's d/d(out) rows are requested first
         {
             PQ_PHASE_IDS();
-            issue_gout(sidx_n, tile + gridDim.x, tid);
+            issue_gout(sidx_n, tile + ngroups, tid);
             if constexpr (K == 1) {
 #pragma unroll
                 for (int i = 0; i < NPRE; ++i) {
@@ -1221,7 +1301,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         stamp(8);
     }
     // ---- this workgroup's slice: every element has one owner
-    float* slice = io.plw_part + (size_t)blockIdx.x * CF::slice_floats(K);
+    float* slice = io.plw_part + (size_t)group * CF::slice_floats(K);
     {
         const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, cq = tid >> 4, l16 = tid & 15;
         const int ot = wave >> 1, ct = wave & 1;
@@ -1243,64 +1323,6 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
     }
     stamp(9);
     stamp.flush(io.stamps, threadIdx.x & 63);
-}
-
-// grads += sum over the workgroups' slices, fixed order (as pg_reduce_kernel: 64 elements per workgroup, four slice groups, compensated)
-template <class ALG, class CF, int K>
-__global__ void __launch_bounds__(256) pq_reduce_kernel(const DevCemlp Cd, const float* part, int nslices) {
-    constexpr int C = CF::C, G = CF::G, P = CF::P, SF = CF::slice_floats(K), SW = CF::slice_w(K);
-    __shared__ float red[4][64];
-    const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + j;
-    float s = 0.f, comp = 0.f;
-    auto add = [&](float v) {
-        const float yk = v - comp, t = s + yk;
-        comp = (t - s) - yk;
-        s = t;
-    };
-    if (e < SF) {
-        for (int sl = q; sl < nslices; sl += 64) {
-            float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = sl + 4 * i < nslices ? part[(size_t)(sl + 4 * i) * SF + e] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) add(v[i]);
-        }
-    }
-    red[q][j] = s;
-    __syncthreads();
-    if (q != 0 || e >= SF) return;
-    s = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
-    const DevBlock& B = Cd.b[K];
-    if (e < SW) {
-        int m = 0, f = e;
-        bool found = false;
-        static_for<0, CF::nmat(K)>([&](auto mm) {
-            constexpr int m_ = decltype(mm)::value;
-            if (!found && e >= CF::woff(K, m_) && e < CF::woff(K, m_) + CF::wmat_floats(K, m_)) { m = m_; f = e - CF::woff(K, m_); found = true; }
-        });
-        const int nct = CF::nct(K, m), which = CF::which(K, m);
-        const int v = f & 3, lane = (f >> 2) & 63;
-        int rest = f >> 8;
-        const int ct = rest % nct; rest /= nct;
-        const int ot = rest & 1, g = rest >> 1;
-        const int o = 16 * ot + 4 * (lane >> 4) + v, cl = 16 * ct + (lane & 15);
-        if (o < C && cl < CF::nch(K, m)) {
-            float* gW = which == 0 ? B.gW1 : (which == 1 ? B.gWR : B.gWL);
-            const int I = which == 0 ? B.I : C;
-            gW[((size_t)o * I + CF::cbase(K, m) + cl) * G + g] += s;
-        }
-    } else {
-        const int f = e - SW, ch = f / CF::kSmall, idx = f % CF::kSmall;
-        if (ch < C) {
-            if (idx < P) B.gw[ch * P + idx] += s;
-            else if (idx < P + G) B.gan[ch * G + (idx - P)] += s;
-            else if (idx >= CF::s_gate && idx < CF::s_gate + 2 * G) { const int g = (idx - CF::s_gate) >> 1; if (idx & 1) B.gsb[ch * G + g] += s; else B.gsa[ch * G + g] += s; }
-            else if (idx == CF::s_b1) { if (B.has_b1) B.gb1[ch] += s; }
-            else if (idx == CF::s_la) B.gla[ch] += s;
-            else if (idx == CF::s_bL) B.gbL[ch] += s;
-        }
-    }
 }
 
 }  // namespace csmpn

@@ -5,7 +5,8 @@
 #include "cemlp_device.hpp"
 
 namespace csmpn {
-// floats of the weight-fragment tables / of one workgroup's gradient slice for (mode, channels, attribute channels); 0: shape not served
+// floats of the weight-fragment tables / of one workgroup's gradient slices (both blocks: each block's launch has its own region) for
+// (mode, channels, attribute channels); 0: shape not served
 size_t cemlp_pq_table_floats_n3(int mode, int channels, int attr);
 size_t cemlp_pq_slice_floats_n3(int mode, int channels, int attr);
 hipError_t launch_cemlp_pq_n3(int mode, int channels, int attr, bool bwd, bool pack, unsigned grid, hipStream_t st, const DevCemlp& C, const RowIO& io,
