@@ -208,10 +208,13 @@ class _CemlpFn(torch.autograd.Function):
         rows = x.shape[0]
         y = torch.empty(rows, binding.out_features, binding.D, dtype=torch.float32, device=x.device)
         ws = binding.workspace(x.device)
-        saved = binding.new_saved(rows, x.device) if any(ctx.needs_input_grad) else None
+        # CSMPN_FLAG_SAVE_STATE: the library honours it for the standalone shapes whose saved buffer has state regions (the
+        # 32-channel Cl(3,0) CEMLPs of the md17 model: csmpn_cemlp_saved_floats sizes them) and ignores it everywhere else
+        saved = binding.new_saved(rows, x.device, _SAVE_STATE) if any(ctx.needs_input_grad) else None
+        ctx.flags = native.FLAG_SAVE_STATE if (_SAVE_STATE and saved is not None) else 0
         check(native.lib().csmpn_cemlp_forward(binding.metric_arr, binding.n, binding.params, binding.nblk,
                                                x.data_ptr(), rows, y.data_ptr(), _ptr(saved), ws.data_ptr(),
-                                               ws.numel(), 0, _stream(x.device)))
+                                               ws.numel(), ctx.flags, _stream(x.device)))
         ctx.binding = binding
         ctx.param_refs = params          # the caller's parameter objects (their .grad, for fused accumulation)
         ctx.ws, ctx.saved = ws, saved   # packed weights / block inputs are reused by backward
@@ -235,7 +238,7 @@ class _CemlpFn(torch.autograd.Function):
         check(native.lib().csmpn_cemlp_backward(binding.metric_arr, binding.n, binding.params, binding.grads,
                                                 binding.nblk, x.data_ptr(), gy.data_ptr(), x.shape[0], _ptr(gx),
                                                 _ptr(ctx.saved), ws.data_ptr(), ws.numel(),
-                                                native.FLAG_WEIGHTS_PACKED,
+                                                native.FLAG_WEIGHTS_PACKED | ctx.flags,
                                                 _stream(x.device)))
         return (gx, None, *views)
 

@@ -643,18 +643,27 @@ unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of
 
 // bytes of the lane kernels' partial buffer (one slice of parameter-gradient sums per workgroup of a backward launch),
 // reserved at the END of the workspace; 0 when the shape is not served by those kernels
+bool cm_bwd_enabled();
 // 16-row-tile MFMA-mixing kernels for Cl(3,0) (cemlp_pq.hpp): weight-fragment tables + one gradient slice per workgroup
 constexpr unsigned kPqGridCap = 768;   // three 4-wave workgroups per CU
-size_t pq_region_bytes(int ch, int i0) {
+size_t pq_region_bytes(int nblk, int ch, int i0) {
     size_t best = 0;
-    for (int mode : {MODE_EDGE, MODE_NODE}) {
-        const int na = mode == MODE_EDGE ? i0 - ch : i0 - 2 * ch;
-        const size_t tf = cemlp_pq_table_floats_n3(mode, ch, na);
+    for (int mode : {MODE_EDGE, MODE_NODE, MODE_PLAIN}) {
+        const int na = mode == MODE_EDGE ? i0 - ch : (mode == MODE_NODE ? i0 - 2 * ch : i0);
+        const size_t tf = cemlp_pq_table_floats_n3(mode, nblk, ch, na);
         if (!tf) continue;
-        const size_t b = (tf + cemlp_pq_slice_floats_n3(mode, ch, na) * kPqGridCap) * sizeof(float) + 1024;
+        const size_t b = (tf + cemlp_pq_slice_floats_n3(mode, nblk, ch, na) * kPqGridCap) * sizeof(float) + 1024;
         best = b > best ? b : best;
     }
     return best;
+}
+// standalone CEMLPs served by the same family (MODE_PLAIN of cemlp_pq.hpp: the md17 embeddings and head): their saved buffer holds,
+// under CSMPN_FLAG_SAVE_STATE, the state regions of the family (one block: nothing else; two blocks: block-1 inputs + hand-over rows)
+bool pq_plain_shape(int n, const csmpn_block_params* blocks, int nblk) {
+    if (n != 3 || nblk < 1 || nblk > 2 || sw().no_pq || sw().no_cm || !cm_bwd_enabled()) return false;
+    for (int k = 0; k < nblk; ++k)
+        if (blocks[k].out_features != 32 || (k > 0 && blocks[k].in_features != 32)) return false;
+    return cemlp_pq_table_floats_n3(MODE_PLAIN, nblk, 32, blocks[0].in_features) != 0;
 }
 size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     if (n != 3 || nblk < 1 || nblk > 2) return 0;
@@ -673,7 +682,7 @@ size_t rl_partial_bytes(int n, const csmpn_block_params* blocks, int nblk) {
     cmf = cmn > cmf ? cmn : cmf;
     const size_t cm = cmf * sizeof(float) * kCmSliceCap;
     const size_t lane = cm > cl ? cm : cl;
-    const size_t pq = pq_region_bytes(ch, i0);   // the same region serves whichever family takes the launch
+    const size_t pq = pq_region_bytes(nblk, ch, i0);   // the same region serves whichever family takes the launch
     return pq > lane ? pq : lane;
 }
 // The channel-MFMA backward (cemlp_cmb.hpp, round 4: two waves per SIMD, tensors parked in LDS) serves the 16-channel
@@ -872,9 +881,10 @@ thread_local bool g_tables_ready = false;
 bool pq_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io, int* channels, int* attr) {
     if (sw().no_pq || sw().no_cm || id != ALG_N3) return false;
     const DevCemlp& C = plan.C;
-    if (C.nblk != 2) return false;
+    if (C.nblk != 2 && !(C.nblk == 1 && mode == MODE_PLAIN)) return false;
     const int ch = C.b[0].O;
-    if (ch != 32 || !C.b[0].w1_sub || C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub) return false;
+    if (ch != 32 || !C.b[0].w1_sub) return false;
+    if (C.nblk == 2 && (C.b[1].O != ch || C.b[1].I != ch || !C.b[1].w1_sub)) return false;
     int na = 0;
     if (mode == MODE_EDGE) {
         if (io.seg[0].ch != ch) return false;
@@ -885,10 +895,12 @@ bool pq_eligible(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io
         na = io.nseg > 2 ? io.seg[2].ch : 0;
         if (C.b[0].I != 2 * ch + na) return false;
     } else {
-        return false;
+        // standalone CEMLP (the md17 embeddings and head): one contiguous input of I0 channels; not the fused embedding
+        if (io.nseg != 1 || io.emb_nperm != 0 || io.seg[0].ch != C.b[0].I) return false;
+        na = C.b[0].I;
     }
-    const size_t tf = cemlp_pq_table_floats_n3(mode, ch, na);
-    if (tf == 0 || !plan.workspace || plan.workspace_bytes < pq_region_bytes(ch, C.b[0].I)) return false;
+    const size_t tf = cemlp_pq_table_floats_n3(mode, C.nblk, ch, na);
+    if (tf == 0 || !plan.workspace || plan.workspace_bytes < pq_region_bytes(C.nblk, ch, C.b[0].I)) return false;
     // the backward runs on the state its forward saved (CSMPN_FLAG_SAVE_STATE, in ITS lane order); without the flag the
     // forward still serves (it writes the row-major block-1 inputs) and the wave-pair backward (cemlp_cmp.hpp) recomputes
     if (bwd && !(io.saved && io.save_state && cm_bwd_enabled())) return false;
@@ -909,17 +921,18 @@ int run_rows(AlgId id, const Plan& plan, int mode, bool bwd, const RowIO& io_in,
             // workgroup on launches below the cap: md17 step 2.11 / 2.28 / 2.43 ms, M32 1.024 / 1.008 / 1.012e8 edges/s: one tile)
             const long want = tiles;
             const unsigned grid = (unsigned)(want < (long)kPqGridCap ? (want > 0 ? want : 1) : kPqGridCap);
-            const size_t tb = cemlp_pq_table_floats_n3(mode, channels, attr) * sizeof(float);
+            const int nblk = plan.C.nblk;
+            const size_t tb = cemlp_pq_table_floats_n3(mode, nblk, channels, attr) * sizeof(float);
             float* tabs = reinterpret_cast<float*>(static_cast<char*>(plan.workspace) + ((plan.workspace_bytes - tb - 16) & ~(size_t)255));
-            io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - cemlp_pq_slice_floats_n3(mode, channels, attr) * sizeof(float) * kPqGridCap);
+            io.plw_part = reinterpret_cast<float*>(reinterpret_cast<char*>(tabs) - cemlp_pq_slice_floats_n3(mode, nblk, channels, attr) * sizeof(float) * kPqGridCap);
             if (bwd) io.plw_g1 = const_cast<float*>(io.saved) + (size_t)io.rows * channels * 8;   // hand-over rows behind the saved block inputs
             if (!cm_bwd_enabled()) io.save_state = 0;   // no state regions in the saved buffer (state_channels())
             bool handled = false;
             if (sw().debug) fprintf(stderr, "[csmpn] pq mode=%d bwd=%d channels=%d attr=%d grid=%u rows=%ld\n", mode, (int)bwd, channels, attr, grid, io.rows);
-            HIP_TRY(launch_cemlp_pq_n3(mode, channels, attr, bwd, !(bwd && g_tables_ready), grid, st, plan.C, io, tabs, &handled));
+            HIP_TRY(launch_cemlp_pq_n3(mode, nblk, channels, attr, bwd, !(bwd && g_tables_ready), grid, st, plan.C, io, tabs, &handled));
             if (handled) {
-                note_kernel("csmpn::cemlp_pq_%s_kernel<%s, ...> (mode %d, %d channels, %d attribute channels)", bwd ? "bwd" : "fwd",
-                            alg_name(id), mode, channels, attr);
+                note_kernel("csmpn::cemlp_pq_%s_kernel<%s, ...> (mode %d, %d channels, %d %s channels, %d block%s)", bwd ? "bwd" : "fwd",
+                            alg_name(id), mode, channels, attr, mode == MODE_PLAIN ? "input" : "attribute", nblk, nblk > 1 ? "s" : "");
                 return CSMPN_OK;
             }
         }
@@ -1351,6 +1364,7 @@ int csmpn_geometric_product_backward(const float* metric, int n, const float* a,
 //   Cl(3,0) 32 channels (cemlp_cm.hpp / cemlp_cmp.hpp)    s, y, R of every block
 //   Cl(5,0) / Cl(4,1), 8 .. 32 channels (cemlp_pl.hpp / cemlp_plw.hpp)   s, y, R of every block, channels padded to groups of 8
 static size_t state_channels(int n, const csmpn_block_params* blocks, int n_blocks) {
+    if (pq_plain_shape(n, blocks, n_blocks)) return (size_t)3 * n_blocks * 32;   // cemlp_pq.hpp, MODE_PLAIN: s, y, R of every block
     if (n_blocks != 2) return 0;
     const size_t ch = (size_t)blocks[0].out_features;
     // (17 .. 32 channels: 32 - the 16-row-tile kernels of cemlp_pg.hpp keep 4 channels per wave, 8 waves per tile)
@@ -1380,8 +1394,8 @@ size_t csmpn_cemlp_saved_floats(int n, const csmpn_block_params* blocks, int n_b
     // the general kernels' hand-over slots (one per saved input: the per-row figure doubles for them) are used by the phased
     // backward only, and make_plan takes that form only from sw().phased_min_rows rows on (the same switch, read once)
     if (base && !cl_shape(n, blocks, n_blocks) && !(n_blocks == 2 && plw_table_bytes(n, blocks, n_blocks)) &&
-        general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows)
-        base /= 2;
+        general_phased_shape(n, blocks, n_blocks) && rows < sw().phased_min_rows && !pq_plain_shape(n, blocks, n_blocks))
+        base /= 2;   // (the 16-row-tile family's standalone CEMLPs always hand d/d(block-1 input) over through the second region)
     const size_t state_rows = (size_t)((rows + 15) & ~(int64_t)15);
     const size_t state = (flags & CSMPN_FLAG_SAVE_STATE) ? state_channels(n, blocks, n_blocks) : 0;
     return ((base * (size_t)rows) << n) + ((state * state_rows) << n);
@@ -1439,6 +1453,8 @@ int csmpn_cemlp_forward(const float* metric, int n, const csmpn_block_params* bl
     io.rows = rows; io.nseg = 1;
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.y = y; io.save = save_inputs;
+    // CSMPN_FLAG_SAVE_STATE: honoured for the shapes whose saved buffer has state regions (pq_plain_shape), ignored otherwise
+    io.save_state = ((flags & CSMPN_FLAG_SAVE_STATE) && pq_plain_shape(n, blocks, n_blocks)) ? 1 : 0;
     return run_rows(id, plan, MODE_PLAIN, false, io, (hipStream_t)stream, need_pack);
 }
 
@@ -1460,9 +1476,14 @@ int csmpn_cemlp_backward(const float* metric, int n, const csmpn_block_params* b
     io.seg[0].a = x; io.seg[0].ch = blocks[0].in_features; io.seg[0].off = 0;
     io.gy = gy; io.gx[0] = gx; io.saved = saved_inputs;
     io.row_store = (flags & CSMPN_FLAG_DETERMINISTIC) ? 1 : 0;   // standalone CEMLP: no row table, atomic-free parameter sums only
-    // CSMPN_FLAG_SAVE_STATE is ignored here, as csmpn_cemlp_forward ignores it (include/csmpn_hip.h): the standalone forward
-    // writes no state regions, so a backward that honoured the flag would read rows nobody wrote
-    return run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
+    // CSMPN_FLAG_SAVE_STATE: honoured exactly where csmpn_cemlp_forward honours it (include/csmpn_hip.h: the shapes of the
+    // 16-row-tile family, whose standalone forward writes the state regions); everywhere else the standalone forward writes
+    // no state, so a backward that honoured the flag would read rows nobody wrote
+    io.save_state = ((flags & CSMPN_FLAG_SAVE_STATE) && pq_plain_shape(n, blocks, n_blocks)) ? 1 : 0;
+    g_tables_ready = io.save_state && (flags & CSMPN_FLAG_WEIGHTS_PACKED) != 0;
+    rc = run_rows(id, plan, MODE_PLAIN, true, io, (hipStream_t)stream, need_pack);
+    g_tables_ready = false;
+    return rc;
 }
 
 // Fused simplex embedding (include/csmpn_hip.h): MODE_PLAIN of the wide parity-lane kernels with the embed descriptor

@@ -82,7 +82,7 @@ template <class ALG, int C_, int MODE_, int NA_>
 struct PgCfg {
     static_assert(ALG::n == 5, "32 blades");
     static_assert(MODE_ == MODE_EDGE || MODE_ == MODE_NODE, "edge or node program");
-    static constexpr int C = C_, MODE = MODE_, NA = NA_, D = ALG::D, G = ALG::G, P = ALG::P;
+    static constexpr int C = C_, MODE = MODE_, NA = NA_, D = ALG::D, G = ALG::G, P = ALG::P, NBLK = 2;
     static_assert(C > 16 && C <= 32 && NA > 0 && NA <= 8, "17 .. 32 channels, one attribute chunk");
     static constexpr int ROW = C * D;
     static constexpr int NST = (C + 3) / 4;           // k-steps of a C-channel operand
@@ -150,7 +150,7 @@ __global__ void pg_pack_kernel(const DevCemlp Cd, float* tabs) {
     const int j = (int)(t & 3);
     int K = 0, m = 0;
     bool found = false, tr = false;
-    static_for<0, 2>([&](auto kk) {
+    static_for<0, CF::NBLK>([&](auto kk) {
         static_for<0, CF::nmat(decltype(kk)::value)>([&](auto mm) {
             constexpr int K_ = decltype(kk)::value, m_ = decltype(mm)::value;
             constexpr int lo = CF::toff(K_, m_), n = CF::mat_f4(K_, m_);

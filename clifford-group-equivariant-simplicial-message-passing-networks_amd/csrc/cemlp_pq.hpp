@@ -38,24 +38,32 @@ constexpr int kPqMaxGroups = 768;                // three workgroups per CU
 // float offset of 16-byte piece p (blades 4p .. 4p+3) of (channel slot c, row r)
 CSMPN_DEV int pq_off(int c, int r, int p) { return c * kPqCS + 8 * r + 4 * (p ^ (r & 1)); }
 
-template <class ALG, int C_, int MODE_, int NA_>
+// MODE_EDGE / MODE_NODE: the EGCL programs (NA_ attribute channels, two blocks). MODE_PLAIN (standalone CEMLP of NBLK_ = 1 or 2 blocks:
+// the simplex embeddings and the head of the md17 model, md17_cssmpnn.py:85-120,165-176): NA_ = the input channels I0 <= 96, taken
+// as chunks of 32 (the last one may be narrower, more than 16 channels wide).
+template <class ALG, int C_, int MODE_, int NA_, int NBLK_ = 2>
 struct PqCfg {
     static_assert(ALG::n == 3, "8 blades");
-    static_assert(MODE_ == MODE_EDGE || MODE_ == MODE_NODE, "edge or node program");
-    static constexpr int C = C_, MODE = MODE_, NA = NA_, D = ALG::D, G = ALG::G, P = ALG::P;
-    static_assert(C == 32 && NA > 0 && NA <= 8 && G == 4 && D == 8 && P % 4 == 0, "32 channels, one attribute chunk");
+    static constexpr int C = C_, MODE = MODE_, NA = NA_, NBLK = NBLK_, D = ALG::D, G = ALG::G, P = ALG::P;
+    static constexpr bool PLAIN = MODE_ == MODE_PLAIN;
+    static_assert(C == 32 && G == 4 && D == 8 && P % 4 == 0 && (NBLK == 1 || NBLK == 2), "32 channels");
+    static_assert(PLAIN ? (NA > 0 && NA <= 96 && (NA % 32 == 0 || NA % 32 > 16)) : (NA > 0 && NA <= 8 && NBLK == 2),
+                  "EGCL: one attribute chunk, two blocks; plain: up to three chunks of 17 .. 32 channels");
     static constexpr int ROW = C * D;
     static constexpr int NST = (C + 3) / 4;           // k-steps of a C-channel operand
     static constexpr int NSTA = (NA + 3) / 4;         // ... of the attribute chunk
     static constexpr int par_stride = 16;             // b1 bL la 0 | sa[4] | sb[4] | sigmoid(an)[4]
     // matrix-chunks ("mats") of a block, in table order (as PgCfg). Block 0: the W1 column blocks of the input chunks, then WR, WL;
     // block 1: W1, WR, WL.  EDGE chunks: [h_dst - h_src (C) in A][edge_attr (NA) in B];  NODE: [h (C) in A][agg (C) in B][node_attr (NA) in E]
-    static constexpr int NCH0 = MODE == MODE_EDGE ? 2 : 3;
-    static constexpr int I0 = MODE == MODE_EDGE ? C + NA : 2 * C + NA;
+    static constexpr int NCH0 = PLAIN ? (NA + 31) / 32 : (MODE == MODE_EDGE ? 2 : 3);
+    static constexpr int I0 = PLAIN ? NA : (MODE == MODE_EDGE ? C + NA : 2 * C + NA);
     static constexpr int nmat(int K) { return K == 0 ? NCH0 + 2 : 3; }
-    static constexpr int nst(int K, int m) { return (K == 0 && m == NCH0 - 1) ? NSTA : NST; }
-    static constexpr int nch(int K, int m) { return (K == 0 && m == NCH0 - 1) ? NA : C; }
-    static constexpr int cbase(int K, int m) { return (K == 0 && m < NCH0) ? (m == NCH0 - 1 ? (NCH0 - 1) * C : m * C) : 0; }
+    static constexpr int nch(int K, int m) {
+        if (K == 0 && m < NCH0) return PLAIN ? (I0 - 32 * m < 32 ? I0 - 32 * m : 32) : (m == NCH0 - 1 ? NA : C);
+        return C;
+    }
+    static constexpr int nst(int K, int m) { return (nch(K, m) + 3) / 4; }
+    static constexpr int cbase(int K, int m) { return (K == 0 && m < NCH0) ? m * C : 0; }
     static constexpr int which(int K, int m) { return K == 0 ? (m < NCH0 ? 0 : m - NCH0 + 1) : m; }   // 0 W1, 1 WR, 2 WL
     static constexpr int ks4(int K, int m) { return (nst(K, m) + 3) / 4; }
     static constexpr int mat_f4(int K, int m) { return G * 2 * ks4(K, m) * 64; }     // [grade][o-tile][s4][lane]
@@ -65,7 +73,7 @@ struct PqCfg {
         for (int q = 0; q < m; ++q) o += mat_f4(K, q);
         return o;
     }
-    static constexpr int fwd_f4 = toff(1, 2) + mat_f4(1, 2);
+    static constexpr int fwd_f4 = toff(NBLK, 0);
     static constexpr int nct(int K, int m) { return (nch(K, m) + 15) / 16; }        // 16-channel tiles of the operand
     static constexpr int tmat_f4(int K, int m) { return G * nct(K, m) * ((NST + 3) / 4) * 64; }   // [grade][c-tile][s4 over the OUT channels][lane]
     static constexpr int ttoff(int K, int m) {
@@ -74,7 +82,7 @@ struct PqCfg {
         for (int q = 0; q < m; ++q) o += tmat_f4(K, q);
         return o;
     }
-    static constexpr int all_f4 = ttoff(1, 2) + tmat_f4(1, 2);
+    static constexpr int all_f4 = ttoff(NBLK, 0);
     static constexpr int tab_floats = 4 * all_f4;
     // backward: slice of block K: mat m at woff(K, m): [grade][o-tile][c-tile][lane][4]; then the per-channel sums [32 channels][kSmall]
     static constexpr int kSmall = 48;      // w[P = 20] | an[4] | 8 pad | (sa, sb)[4] | b1 | la | bL | 5 pad
@@ -84,7 +92,7 @@ struct PqCfg {
     static constexpr int woff(int K, int m) { int o = 0; for (int q = 0; q < m; ++q) o += wmat_floats(K, q); return o; }
     static constexpr int slice_w(int K) { return woff(K, nmat(K)); }
     static constexpr int slice_floats(int K) { return slice_w(K) + 32 * kSmall; }
-    static constexpr int slice_max = slice_floats(0) > slice_floats(1) ? slice_floats(0) : slice_floats(1);
+    static constexpr int slice_both = slice_floats(0) + (NBLK > 1 ? slice_floats(1) : 0);   // each block's launch has its own region
     // LDS (floats). backward: A | B | E (8 slots) | two row-sum arrays [4 waves][16 rows] | path weights and parameters of ONE block | indices
     static constexpr int b_E = 2 * kPqBuf, b_ln = b_E + 8 * kPqCS, b_w = b_ln + 2 * kPqWaves * kPqRows, b_par = b_w + 32 * P,
                          b_idx = b_par + 32 * par_stride, bwd_lds_floats = b_idx + 128;
@@ -208,6 +216,12 @@ CSMPN_DEV void pq_load_state(float (&t)[8], const float* p) {
 // the piece is the lane; index-array entries of such a row are scalars too (row pointers in SGPRs, scalar validity branches)
 CSMPN_DEV int pq_row_of(int t, int i) { return __builtin_amdgcn_readfirstlane(t >> 6) + 4 * i; }
 CSMPN_DEV int pq_sidx(const int* a, int k) { return __builtin_amdgcn_readfirstlane(a[k]); }
+// state region of tensor t (0 s, 1 y, 2 R) and block K behind the saved block inputs + hand-over rows (two-block programs: as
+// cemlp_device.hpp::state_region; one block: the regions alone)
+template <int ROW, int NBLK>
+CSMPN_DEV size_t pq_state_region(long rows, int t, int K) {
+    return (NBLK == 2 ? (size_t)2 * rows * ROW : 0) + (size_t)(NBLK * t + K) * state_rows(rows) * ROW;
+}
 // sum over the four lanes n, n + 16, n + 32, n + 48 of a wave (the four channel groups of a row)
 CSMPN_DEV float pq_sum_q(float v) {
     v += __shfl_xor(v, 16);
@@ -258,6 +272,8 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     const RowIO& io = *(const RowIO*)(const char*)(ka + kIoOffset);
     (void)C_arg; (void)io_arg;
     constexpr int C = CF::C, MODE = CF::MODE, NA = CF::NA, D = 8, G = 4, P = CF::P, ROW = CF::ROW, NST = CF::NST;
+    constexpr bool PLAIN = CF::PLAIN;
+    constexpr int NBLK = CF::NBLK, I0 = CF::I0, NCH0 = CF::NCH0;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const bufA = smem + CF::o_A;
     float* const bufB = smem + CF::o_B;
@@ -265,8 +281,8 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     float* const lnx = smem + CF::o_ln;
     int* sidx = reinterpret_cast<int*>(smem + CF::o_idx);            // this tile's [0..15] target / row, [16..31] source, [32..47] attribute row,
     int* sidx_n = sidx + 64;                                          // [48..63] node program: 1 / max(deg, 1) (float); the next tile's in the other half
-    constexpr int PPR = C * 2, PPA = 4 * CF::NSTA * 2;                // 16-byte pieces per row: a C-channel segment, the attribute chunk padded to whole k-steps
-    constexpr int NPRE = PPR * kPqRows / kPqThreads, NPA = (PPA * kPqRows + kPqThreads - 1) / kPqThreads;
+    constexpr int PPR = C * 2, PPA = PLAIN ? 1 : 4 * CF::NSTA * 2;   // 16-byte pieces per row: a C-channel segment, the attribute chunk padded to whole k-steps
+    constexpr int NPRE = PPR * kPqRows / kPqThreads, NPA = PLAIN ? 1 : (PPA * kPqRows + kPqThreads - 1) / kPqThreads;
     static_assert(NPRE * kPqThreads == PPR * kPqRows && PPR == 64, "whole pieces per thread, one row per wave and piece index (pq_row_of)");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = tid & 15, cq = tid >> 4;                            // ROW layout: channels cq, cq + 16
@@ -274,8 +290,8 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     const f4* tabs = reinterpret_cast<const f4*>(io.plw_tabs);
     PgStamp stamp(0);
 
-    // per-channel parameters and path weights of both blocks -> LDS
-    static_for<0, 2>([&](auto kk) {
+    // per-channel parameters and path weights of the blocks -> LDS
+    static_for<0, NBLK>([&](auto kk) {
         constexpr int K = decltype(kk)::value;
         const DevBlock& B = Cd.b[K];
         for (int e = tid; e < 32 * CF::par_stride; e += kPqThreads) {
@@ -307,11 +323,17 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         } else {
             dst[t] = valid ? t : -1;
             float sc = 1.0f;
-            if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            if constexpr (MODE == MODE_NODE) {
+                if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            }
             reinterpret_cast<float*>(dst)[48 + t] = sc;
         }
     };
-    f4 pre_a[NPRE], pre_b[NPRE], pre_x[NPA];
+    // plain program: input chunk m of row `row` (pieces 64 m .. 64 m + 63 of the I0-channel row; zero beyond it)
+    auto plain_piece = [&](long row, int m, int e) {
+        return 64 * m + e < 2 * I0 ? pg_ld4(io.seg[0].a + (size_t)row * (I0 * D) + 256 * m + 4 * e) : f4{0.f, 0.f, 0.f, 0.f};
+    };
+    f4 pre_a[NPRE], pre_b[NPRE], pre_x[PLAIN && NCH0 == 3 ? NPRE : NPA];
     auto issue_rows = [&](const int* idx, long tile_, int t) {
         const float* sc_ = reinterpret_cast<const float*>(idx) + 48;
         // the index reads of all rows first (one LDS round trip), then the scalar row pointers and the loads
@@ -331,23 +353,30 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         for (int i = 0; i < NPRE; ++i) {
             const int rr = pq_row_of(t, i), e = t & 63;
             pre_a[i] = pre_b[i] = f4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PLAIN && NCH0 == 3) pre_x[i] = f4{0.f, 0.f, 0.f, 0.f};
             if (ia[i] >= 0) {
                 if constexpr (MODE == MODE_EDGE) {
                     pre_a[i] = pg_ld4(io.seg[0].a + (size_t)ia[i] * ROW + 4 * e);
                     pre_b[i] = pg_ld4(io.seg[0].b + (size_t)ib[i] * ROW + 4 * e);
+                } else if constexpr (PLAIN) {
+                    pre_a[i] = plain_piece(tile_ * kPqRows + rr, 0, e);
+                    if constexpr (NCH0 >= 2) pre_b[i] = plain_piece(tile_ * kPqRows + rr, 1, e);
+                    if constexpr (NCH0 == 3) pre_x[i] = plain_piece(tile_ * kPqRows + rr, 2, e);
                 } else {
                     pre_a[i] = pg_ld4(io.seg[0].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e);
                     pre_b[i] = pg_ld4(io.seg[1].a + (size_t)(tile_ * kPqRows + rr) * ROW + 4 * e) * sc_[rr];
                 }
             }
         }
+        if constexpr (!PLAIN) {
 #pragma unroll
-        for (int i = 0; i < NPA; ++i) {
-            const int p = t + i * kPqThreads, rr = (p / PPA) & 15, e = p % PPA;
-            pre_x[i] = f4{0.f, 0.f, 0.f, 0.f};
-            if (p < kPqRows * PPA && idx[rr] >= 0 && e < NA * 2) {
-                if constexpr (MODE == MODE_EDGE) pre_x[i] = pg_ld4(io.seg[1].a + (size_t)idx[32 + rr] * (NA * D) + 4 * e);
-                else pre_x[i] = pg_ld4(io.seg[2].a + (size_t)(tile_ * kPqRows + rr) * (NA * D) + 4 * e);
+            for (int i = 0; i < NPA; ++i) {
+                const int p = t + i * kPqThreads, rr = (p / PPA) & 15, e = p % PPA;
+                pre_x[i] = f4{0.f, 0.f, 0.f, 0.f};
+                if (p < kPqRows * PPA && idx[rr] >= 0 && e < NA * 2) {
+                    if constexpr (MODE == MODE_EDGE) pre_x[i] = pg_ld4(io.seg[1].a + (size_t)idx[32 + rr] * (NA * D) + 4 * e);
+                    else pre_x[i] = pg_ld4(io.seg[2].a + (size_t)(tile_ * kPqRows + rr) * (NA * D) + 4 * e);
+                }
             }
         }
     };
@@ -355,13 +384,16 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
     __syncthreads();
     issue_rows(sidx, blockIdx.x, tid);
     // weight fragments of the first MIX phase of a tile (requested at the end of the previous tile, in front of its stores / atomics)
-    PqA<NST> aW0;
-    PqA<MODE == MODE_NODE ? NST : 1> aW0g;      // node program: the aggregate's chunk
-    PqA<CF::NSTA> aW0x;
+    // (chunk m of the plain program: CF::nst(0, m) k-steps - the last chunk may be narrower)
+    constexpr int NST1 = PLAIN ? (NCH0 >= 2 ? CF::nst(0, 1) : 1) : (MODE == MODE_NODE ? NST : 1);
+    constexpr int NSTX = PLAIN ? (NCH0 == 3 ? CF::nst(0, 2) : 1) : CF::NSTA;
+    PqA<PLAIN ? CF::nst(0, 0) : NST> aW0;
+    PqA<NST1> aW0g;      // node program: the aggregate's chunk; plain: chunk 1
+    PqA<NSTX> aW0x;      // attribute chunk; plain: chunk 2
     auto load_w0 = [&]() {
-        pq_load_a<NST>(aW0, tabs + CF::toff(0, 0), lane, mp, mot, 2);
-        if constexpr (MODE == MODE_NODE) pq_load_a<NST>(aW0g, tabs + CF::toff(0, 1), lane, mp, mot, 2);
-        pq_load_a<CF::NSTA>(aW0x, tabs + CF::toff(0, CF::NCH0 - 1), lane, mp, mot, 2);
+        pq_load_a(aW0, tabs + CF::toff(0, 0), lane, mp, mot, 2);
+        if constexpr (MODE == MODE_NODE || (PLAIN && NCH0 >= 2)) pq_load_a(aW0g, tabs + CF::toff(0, 1), lane, mp, mot, 2);
+        if constexpr (!PLAIN || NCH0 == 3) pq_load_a(aW0x, tabs + CF::toff(0, CF::NCH0 - 1), lane, mp, mot, 2);
     };
     load_w0();
     stamp(0);
@@ -377,14 +409,16 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                     pg_st4(bufA + pq_off(e >> 1, rr, e & 1), pre_a[i] - pre_b[i]);
                 } else {
                     pg_st4(bufA + pq_off(e >> 1, rr, e & 1), pre_a[i]);
-                    pg_st4(bufB + pq_off(e >> 1, rr, e & 1), pre_b[i]);
+                    if constexpr (!PLAIN || NCH0 >= 2) pg_st4(bufB + pq_off(e >> 1, rr, e & 1), pre_b[i]);
                 }
             }
-            float* const bufX = MODE == MODE_EDGE ? bufB : bufE;
+            if constexpr (!PLAIN) {
+                float* const bufX = MODE == MODE_EDGE ? bufB : bufE;
 #pragma unroll
-            for (int i = 0; i < NPA; ++i) {
-                const int p = tid + i * kPqThreads, rr = (p / PPA) & 15, e = p % PPA;
-                if (p < kPqRows * PPA) pg_st4(bufX + pq_off(e >> 1, rr, e & 1), pre_x[i]);
+                for (int i = 0; i < NPA; ++i) {
+                    const int p = tid + i * kPqThreads, rr = (p / PPA) & 15, e = p % PPA;
+                    if (p < kPqRows * PPA) pg_st4(bufX + pq_off(e >> 1, rr, e & 1), pre_x[i]);
+                }
             }
             if (tid < kPqRows) load_idx(sidx_n, tile + gridDim.x, tid);
         }
@@ -392,7 +426,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
         stamp(1);
 
         PqA<NST> aW1;     // block 1's W1 fragments: requested in front of block 0's last ROW phase
-        static_for<0, 2>([&](auto kk) {
+        static_for<0, NBLK>([&](auto kk) {
             constexpr int K = decltype(kk)::value;
             const float* parb = smem + CF::o_par + K * 32 * CF::par_stride;
             const float* wb = smem + CF::o_w + K * 32 * P;
@@ -401,12 +435,24 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 f4 acc[4];
                 pq_zero(acc);
                 if constexpr (K == 0) {
-                    pq_mix_run<NST>(acc, bufA, aW0, lane, mp);
+                    pq_mix_run(acc, bufA, aW0, lane, mp);
                     if constexpr (MODE == MODE_EDGE) {
-                        pq_mix_run<CF::NSTA>(acc, bufB, aW0x, lane, mp);
+                        pq_mix_run(acc, bufB, aW0x, lane, mp);
+                    } else if constexpr (PLAIN) {
+                        if constexpr (NCH0 >= 2) pq_mix_run(acc, bufB, aW0g, lane, mp);
+                        if constexpr (NCH0 == 3) {   // the third chunk follows through B
+                            __syncthreads();
+#pragma unroll
+                            for (int i = 0; i < NPRE; ++i) {
+                                const int rr = pq_row_of(tid, i), e = tid & 63;
+                                pg_st4(bufB + pq_off(e >> 1, rr, e & 1), pre_x[i]);
+                            }
+                            __syncthreads();
+                            pq_mix_run(acc, bufB, aW0x, lane, mp);
+                        }
                     } else {
-                        pq_mix_run<NST>(acc, bufB, aW0g, lane, mp);
-                        pq_mix_run<CF::NSTA>(acc, bufE, aW0x, lane, mp);
+                        pq_mix_run(acc, bufB, aW0g, lane, mp);
+                        pq_mix_run(acc, bufE, aW0x, lane, mp);
                     }
                     __syncthreads();          // the other output tile's wave reads the same piece of A
                 } else {
@@ -439,7 +485,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 pq_ld8(y, bufA, r, c);
                 y[0] += par[0];
                 if (save_state && rvalid)
-                    pq_store_state(io.save + state_region<ROW, ROW>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv), y);
+                    pq_store_state(io.save + pq_state_region<ROW, CF::NBLK>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv), y);
                 static_for<0, G>([&](auto g) {
                     constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
                     float u;
@@ -474,7 +520,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
             __syncthreads();
             stamp(3 + 6 * K);
             // ---- ROW: normalisation, geometric product, layer norm (block 0: block 1's W1 fragments first)
-            if constexpr (K == 0) pq_load_a<NST>(aW1, tabs + CF::toff(1, 0), lane, mp, mot, 2);
+            if constexpr (K == 0 && NBLK > 1) pq_load_a<NST>(aW1, tabs + CF::toff(1, 0), lane, mp, mot, 2);
             float s[2][8];
             float nl[2];
             static_for<0, 2>([&](auto mm) {
@@ -486,7 +532,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 pq_ld8(s[mv], bufA, r, c);     // s accumulates: linear_left output + product
                 s[mv][0] += par[1];
                 if (save_state && rvalid)
-                    pq_store_state(io.save + state_region<ROW, ROW>(io.rows, 2, K) + pq_state_off(tile, wave, lane, mv), R);
+                    pq_store_state(io.save + pq_state_region<ROW, CF::NBLK>(io.rows, 2, K) + pq_state_off(tile, wave, lane, mv), R);
                 static_for<0, G>([&](auto g) {
                     constexpr int d0 = ALG::gstart(g), nd = ALG::gsize(g);
                     float qq = 0.f;
@@ -507,7 +553,7 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                     qs = __builtin_fmaf(qsf<ALG, d> * s[mv][d], s[mv][d], qs);
                 });
                 if (save_state && rvalid)
-                    pq_store_state(io.save + state_region<ROW, ROW>(io.rows, 0, K) + pq_state_off(tile, wave, lane, mv), s[mv]);
+                    pq_store_state(io.save + pq_state_region<ROW, CF::NBLK>(io.rows, 0, K) + pq_state_off(tile, wave, lane, mv), s[mv]);
                 nl[mv] = sqrt_pos(sqrt_pos(__builtin_fmaf(qs, qs, kSmooth)));
             });
             {
@@ -525,8 +571,8 @@ __global__ void __launch_bounds__(kPqThreads, 3) cemlp_pq_fwd_kernel(const DevCe
                 float out[8];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) out[d] = kf * s[mv][d];
-                // block 0: the block-1 input -> B (R has been read by its own lane only); block 1: rows -> A
-                pq_st8(K == 0 ? bufB : bufA, r, c, out);
+                // the last block: rows -> A; block 0 of two: the block-1 input -> B (R has been read by its own lane only)
+                pq_st8(K == NBLK - 1 ? bufA : bufB, r, c, out);
             });
             __syncthreads();
             stamp(7 + 6 * K);
@@ -804,6 +850,8 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
     const int ngroups = aux.groups;                 // workgroups that walk the tiles
     const int group = (int)blockIdx.x - nred;       // ... and this one's index among them
     constexpr int C = CF::C, MODE = CF::MODE, NA = CF::NA, D = 8, G = 4, P = CF::P, ROW = CF::ROW, NST = CF::NST;
+    constexpr bool PLAIN = CF::PLAIN, LAST = K == CF::NBLK - 1;     // LAST: d/d(out) comes from the caller, not from the hand-over rows
+    constexpr int I0 = CF::I0, NCH0 = CF::NCH0;
     constexpr int PPR = C * 2;
     constexpr int NM = CF::nmat(K), mR = NM - 2, mL = NM - 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -851,9 +899,15 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         } else {
             dst[t] = valid ? t : -1;
             float sc = 1.0f;
-            if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            if constexpr (MODE == MODE_NODE) {
+                if (valid && io.seg[1].deg) { const int dg = io.seg[1].deg[row]; sc = 1.0f / float(dg > 1 ? dg : 1); }
+            }
             reinterpret_cast<float*>(dst)[48 + t] = sc;
         }
+    };
+    // plain program: input chunk m of row `row` (pieces 64 m .. 64 m + 63 of the I0-channel row; zero beyond it)
+    auto plain_piece = [&](long row, int m, int e) {
+        return 64 * m + e < 2 * I0 ? pg_ld4(io.seg[0].a + (size_t)row * (I0 * D) + 256 * m + 4 * e) : f4{0.f, 0.f, 0.f, 0.f};
     };
     f4 pre[NPRE];
     auto issue_gout = [&](const int* idx, long tile_, int t) {
@@ -867,7 +921,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             const int rr = pq_row_of(t, i), e = t & 63;
             pre[i] = f4{0.f, 0.f, 0.f, 0.f};
             if (ia[i] >= 0) {
-                if constexpr (K == 1) {
+                if constexpr (LAST) {
                     const size_t grow = MODE == MODE_EDGE ? (size_t)ia[i] : (size_t)(tile_ * kPqRows + rr);
                     pre[i] = pg_ld4(io.gy + grow * ROW + 4 * e);
                 } else {
@@ -892,8 +946,8 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
 #pragma unroll
                 for (int d = 0; d < 8; ++d) { s_st[mv][d] = 0.f; y_st[mv][d] = 0.f; }
                 if (live) {
-                    pq_load_state(s_st[mv], io.saved + state_region<ROW, ROW>(io.rows, 0, K) + pq_state_off(tile, wave, lane, mv));
-                    pq_load_state(y_st[mv], io.saved + state_region<ROW, ROW>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv));
+                    pq_load_state(s_st[mv], io.saved + pq_state_region<ROW, CF::NBLK>(io.rows, 0, K) + pq_state_off(tile, wave, lane, mv));
+                    pq_load_state(y_st[mv], io.saved + pq_state_region<ROW, CF::NBLK>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv));
                 }
             }
             // ---- d/d(block output) rows (requested during the previous tile) -> A
@@ -986,7 +1040,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             for (int mv = 0; mv < 2; ++mv) {
 #pragma unroll
                 for (int d = 0; d < 8; ++d) R_st[mv][d] = 0.f;
-                if (live) pq_load_state(R_st[mv], io.saved + state_region<ROW, ROW>(io.rows, 2, K) + pq_state_off(tile, wave, lane, mv));
+                if (live) pq_load_state(R_st[mv], io.saved + pq_state_region<ROW, CF::NBLK>(io.rows, 2, K) + pq_state_off(tile, wave, lane, mv));
             }
             f4 acc[4];
             pq_zero(acc);
@@ -1066,7 +1120,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             for (int mv = 0; mv < 2; ++mv) {
 #pragma unroll
                 for (int d = 0; d < 8; ++d) y2_st[mv][d] = 0.f;
-                if (live) pq_load_state(y2_st[mv], io.saved + state_region<ROW, ROW>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv));
+                if (live) pq_load_state(y2_st[mv], io.saved + pq_state_region<ROW, CF::NBLK>(io.rows, 1, K) + pq_state_off(tile, wave, lane, mv));
             }
             f4 acc[4];
             pq_zero(acc);
@@ -1082,7 +1136,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         f4 xa[NPRE], xb[K == 0 && MODE == MODE_EDGE ? NPRE : 1];
         {
             PQ_PHASE_IDS();
-            pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);     // W1^T: in front of the gathers
+            if constexpr (!(PLAIN && K == 0)) pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);     // W1^T: in front of the gathers
             int ia[NPRE], ib[NPRE];
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
@@ -1105,10 +1159,11 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                     else if constexpr (MODE == MODE_EDGE) {
                         xa[i] = pg_ld4(io.seg[0].a + (size_t)ia[i] * ROW + 4 * e);
                         xb[i] = pg_ld4(io.seg[0].b + (size_t)ib[i] * ROW + 4 * e);
-                    } else xa[i] = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
+                    } else if constexpr (PLAIN) xa[i] = plain_piece(row0 + rr, 0, e);
+                    else xa[i] = pg_ld4(io.seg[0].a + (size_t)(row0 + rr) * ROW + 4 * e);
                 }
             }
-            if constexpr (K == 0) {
+            if constexpr (K == 0 && !PLAIN) {
                 constexpr int PPA = 8 * 2;   // the 8 attribute slots of E (the rows-contracting MFMA reads all of them)
                 static_assert(kPqRows * PPA == kPqThreads, "one attribute piece per thread");
                 const int rr = tid / PPA, e = tid % PPA;
@@ -1176,7 +1231,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         __syncthreads();
         stamp(6);
         // ---- MIX: d/dW1 += gy^T x, gx = W1^T gy
-        if constexpr (K == 1 || MODE == MODE_EDGE) {
+        if constexpr (K >= 1 || MODE == MODE_EDGE) {
             PQ_PHASE_IDS();
             f4 acc[4];
             pq_zero(acc);
@@ -1195,6 +1250,50 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             __syncthreads();
             pq_write_d(bufB, acc, lane, mp, mot);
             if constexpr (K == 0) { if (want_a) pq_write_d<8>(bufE, acca, lane, mp, 0); }
+        } else if constexpr (PLAIN) {
+            // plain program, block 0: input chunk 0 in A now, the others follow through A; every chunk's d/dx leaves as soon as it is there
+            PQ_PHASE_IDS();
+            static_for<0, NCH0>([&](auto mm) {
+                constexpr int m = decltype(mm)::value;
+                constexpr int NSTm = CF::nst(0, m);
+                f4 accx[4];
+                const bool want_x = io.gx[0] != nullptr;
+                f4 nxt[NPRE];          // the next chunk's rows travel under the MFMAs
+                if constexpr (m + 1 < NCH0) {
+#pragma unroll
+                    for (int i = 0; i < NPRE; ++i) {
+                        const int rr = pq_row_of(tid, i), e = tid & 63;
+                        nxt[i] = row0 + rr < io.rows ? plain_piece(row0 + rr, m + 1, e) : f4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                if (want_x) {
+                    pq_zero(accx);
+                    PqA<NST> aX;
+                    pq_load_a<NST>(aX, tabs + CF::ttoff(0, m), lane, mp, mot, 2);
+                    pq_mix_run<NST>(accx, bufB, aX, lane, mp);
+                }
+                pq_wgrad(m == 0 ? accW0 : (m == 1 ? accW1 : accW2), bufB, bufA, wave, lane);
+                __syncthreads();             // every wave is done with this chunk in A
+                if (want_x) {
+                    pq_write_d(bufA, accx, lane, mp, mot);
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < NPRE; ++i) {
+                        const int rr = pq_row_of(tid, i), e = tid & 63;
+                        if (row0 + rr < io.rows && 64 * m + e < 2 * I0)
+                            pg_st4(io.gx[0] + (size_t)(row0 + rr) * (I0 * D) + 256 * m + 4 * e, pg_ld4(bufA + pq_off(e >> 1, rr, e & 1)));
+                    }
+                    if constexpr (m + 1 < NCH0) __syncthreads();
+                }
+                if constexpr (m + 1 < NCH0) {
+#pragma unroll
+                    for (int i = 0; i < NPRE; ++i) {
+                        const int rr = pq_row_of(tid, i), e = tid & 63;
+                        pg_st4(bufA + pq_off(e >> 1, rr, e & 1), nxt[i]);
+                    }
+                    __syncthreads();
+                }
+            });
         } else {
             // node program, block 0: h in A now; the aggregate follows through A, the attributes sit in E
             PQ_PHASE_IDS();
@@ -1238,6 +1337,8 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                     const int rr = pq_row_of(tid, i), e = tid & 63;
                     if (row0 + rr < io.rows) pg_st4(io.plw_g1 + (size_t)(row0 + rr) * ROW + 4 * e, pg_ld4(bufB + pq_off(e >> 1, rr, e & 1)));
                 }
+            } else if constexpr (PLAIN) {
+                // (every chunk's d/dx rows left in the MIX phase above)
             } else if constexpr (MODE == MODE_EDGE) {
                 if (io.gx[0]) {
                     if (io.row_store) {
@@ -1311,6 +1412,9 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         if constexpr (K == 0) {
             if constexpr (MODE == MODE_EDGE) {
                 pq_store_unit<1>(slice + CF::woff(0, 1), accW1, ot, 0, lane, 2 * ct, 2);
+            } else if constexpr (PLAIN) {
+                if constexpr (NCH0 >= 2) pq_store_unit<2>(slice + CF::woff(0, 1), accW1, ot, ct, lane, 0, 4);
+                if constexpr (NCH0 == 3) pq_store_unit<2>(slice + CF::woff(0, 2), accW2, ot, ct, lane, 0, 4);
             } else {
                 pq_store_unit<2>(slice + CF::woff(0, 1), accW1, ot, ct, lane, 0, 4);
                 pq_store_unit<1>(slice + CF::woff(0, 2), accW2, ot, 0, lane, 2 * ct, 2);

@@ -5,10 +5,10 @@
 #include "cemlp_device.hpp"
 
 namespace csmpn {
-// floats of the weight-fragment tables / of one workgroup's gradient slices (both blocks: each block's launch has its own region) for
-// (mode, channels, attribute channels); 0: shape not served
-size_t cemlp_pq_table_floats_n3(int mode, int channels, int attr);
-size_t cemlp_pq_slice_floats_n3(int mode, int channels, int attr);
-hipError_t launch_cemlp_pq_n3(int mode, int channels, int attr, bool bwd, bool pack, unsigned grid, hipStream_t st, const DevCemlp& C, const RowIO& io,
-                              float* tabs, bool* handled);
+// floats of the weight-fragment tables / of one workgroup's gradient slices (all blocks: each block's launch has its own region) for
+// (mode, blocks, channels, attribute channels - MODE_PLAIN: input channels of block 0); 0: shape not served
+size_t cemlp_pq_table_floats_n3(int mode, int nblk, int channels, int attr);
+size_t cemlp_pq_slice_floats_n3(int mode, int nblk, int channels, int attr);
+hipError_t launch_cemlp_pq_n3(int mode, int nblk, int channels, int attr, bool bwd, bool pack, unsigned grid, hipStream_t st, const DevCemlp& C,
+                              const RowIO& io, float* tabs, bool* handled);
 }  // namespace csmpn

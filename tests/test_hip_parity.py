@@ -1022,6 +1022,22 @@ def _cemlp_case(pkg, metric, in_f, hid, out_f, nl, rows, seed, slack=4.0):
         check(f"{tag}.g.{k}", prm.grad.cpu().numpy(), p64[k].grad.numpy(), p32[k].grad.numpy(), slack=slack)
 
 
+@pytest.mark.parametrize("in_f,nl,rows", [(60, 1, 1203), (90, 2, 777), (32, 1, 940), (90, 2, 5)], ids=["60x1", "90x2", "32x1", "90x2-5rows"])
+def test_standalone_cemlp_on_the_16_row_tile_family(pkg, in_f, nl, rows):
+    """Round 5: the standalone 32-channel Cl(3,0) CEMLPs of the md17 model (simplex embeddings 60 -> 32 and 90 -> 32 -> 32, head
+    32 -> 32: md17_cssmpnn.py:85-120,165-176) run on MODE_PLAIN of the 16-row-tile family (cemlp_pq.hpp: input chunks of 32
+    channels, the last one narrower; one or two blocks; save-state backward) instead of the general row-tile kernels. Output,
+    d/dx and every parameter gradient against the float64 oracle; the dispatch is checked by name."""
+    from csmpn_hip import native
+    _cemlp_case(pkg, [1.0, 1.0, 1.0], in_f, 32, 32, nl, rows, seed=100 + in_f + nl)
+    # the forward of a fresh call on this thread names the family (autograd's backward runs on its own thread)
+    m = pkg.CEMLP(pkg.CliffordAlgebra((1.0, 1.0, 1.0)), in_f, 32, 32, n_layers=nl).to(dev())
+    m(torch.randn(rows, in_f, 8, device=dev()))
+    torch.cuda.synchronize()
+    name = native.lib().csmpn_last_kernel().decode()
+    assert "cemlp_pq_fwd_kernel" in name and f"{in_f} input channels" in name, name
+
+
 def test_cemlp_shape_sweep(pkg):
     """Seeded sweep over channel counts that are not multiples of 4 / 8 / 16, 1- and 2-block CEMLPs and
     ragged row counts (partial tiles, fewer rows than a tile), Cl(3,0), Cl(2,0) and Cl(5,0): every k-block
