@@ -71,7 +71,10 @@ extern "C" {
                                        csmpn_egcl_node_forward/backward and csmpn_cemlp_forward/backward, where it only
                                        selects the atomic-free parameter sums. */
 #define CSMPN_FLAG_SAVE_STATE 8u     /* csmpn_egcl_{edge,node}_{forward,backward}, csmpn_embed_cemlp_{forward,backward} (two-block
-                                      * modules), round 4: the forward ALSO stores, per block,
+                                      * modules), round 4; csmpn_cemlp_{forward,backward}, round 5, for the standalone Cl(3,0) CEMLPs
+                                      * of 32 channels the 16-row-tile family serves (1 or 2 blocks; 32, 60 or 90 input channels:
+                                      * csmpn_cemlp_saved_floats(..., CSMPN_FLAG_SAVE_STATE) > the size without the flag tells)
+                                      * and ignored by them for every other shape: the forward ALSO stores, per block,
                                       * what the backward would otherwise recompute, in "state regions" behind the saved block
                                       * inputs and the hand-over region (csmpn_cemlp_saved_floats sizes them), and the backward
                                       * called with the same flag reads them:
