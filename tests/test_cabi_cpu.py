@@ -154,3 +154,28 @@ def test_flat_parameters_guard_against_set_to_none(pkg):
     assert flat_gradients_intact(flat) and float(m[1].bias.grad.abs().sum()) == 0.0
     opt.zero_grad()                                          # set_to_none=True: the aliasing is gone
     assert not flat_gradients_intact(flat)
+
+
+def test_saved_buffer_sizes_of_the_standalone_32_channel_cemlps(pkg):
+    """csmpn_cemlp_saved_floats is the sizing contract of the saved buffer (host-side query, no GPU): for the standalone
+    32-channel Cl(3,0) CEMLPs that the 16-row-tile family serves (the md17 embeddings 60 -> 32, 90 -> 32 -> 32 and the head
+    32 -> 32) CSMPN_FLAG_SAVE_STATE adds three state regions per block of whole 16-row tiles; one-block modules have nothing
+    else in the buffer, two-block modules the block-1 inputs + the hand-over rows in front - at every row count, also below
+    the general kernels' phased-backward threshold. Shapes outside the family are not touched by the flag."""
+    from csmpn_hip import native, ops
+    lib = native.lib()
+    metric = (1.0, 1.0, 1.0)
+    rows = 1001
+    tiles16 = (rows + 15) // 16 * 16
+    for in_f, nblk in ((60, 1), (90, 2), (32, 1)):
+        specs = [dict(in_features=in_f if k == 0 else 32, out_features=32) for k in range(nblk)]
+        b = ops.CemlpBinding(metric, specs)
+        plain = int(lib.csmpn_cemlp_saved_floats(b.n, b.params, b.nblk, rows, 0))
+        state = int(lib.csmpn_cemlp_saved_floats(b.n, b.params, b.nblk, rows, native.FLAG_SAVE_STATE))
+        base = 2 * 32 * 8 * rows if nblk == 2 else 0
+        assert plain == base and state == base + 3 * nblk * 32 * 8 * tiles16, (in_f, nblk, plain, state)
+        assert int(lib.csmpn_cemlp_saved_floats_per_row(b.n, b.params, b.nblk)) > 0
+        assert int(lib.csmpn_cemlp_workspace_bytes(b.n, b.params, b.nblk)) > 768 * 4 * 32 * 48   # tables + one slice per workgroup
+    # a 16-channel standalone CEMLP (the motion model's): no state regions, whatever the flag
+    b = ops.CemlpBinding(metric, [dict(in_features=40, out_features=16), dict(in_features=16, out_features=16)])
+    assert lib.csmpn_cemlp_saved_floats(b.n, b.params, b.nblk, rows, 0) == lib.csmpn_cemlp_saved_floats(b.n, b.params, b.nblk, rows, native.FLAG_SAVE_STATE)
