@@ -210,8 +210,10 @@ class _CemlpFn(torch.autograd.Function):
         ws = binding.workspace(x.device)
         # CSMPN_FLAG_SAVE_STATE: the library honours it for the standalone shapes whose saved buffer has state regions (the
         # 32-channel Cl(3,0) CEMLPs of the md17 model: csmpn_cemlp_saved_floats sizes them) and ignores it everywhere else
-        saved = binding.new_saved(rows, x.device, _SAVE_STATE) if any(ctx.needs_input_grad) else None
-        ctx.flags = native.FLAG_SAVE_STATE if (_SAVE_STATE and saved is not None) else 0
+        # (asked for only where the standalone entry points honour it: other shapes would get state regions sized and never used)
+        want_state = _SAVE_STATE and binding.n == 3 and binding.out_features == 32
+        saved = binding.new_saved(rows, x.device, want_state) if any(ctx.needs_input_grad) else None
+        ctx.flags = native.FLAG_SAVE_STATE if (want_state and saved is not None) else 0
         check(native.lib().csmpn_cemlp_forward(binding.metric_arr, binding.n, binding.params, binding.nblk,
                                                x.data_ptr(), rows, y.data_ptr(), _ptr(saved), ws.data_ptr(),
                                                ws.numel(), ctx.flags, _stream(x.device)))
