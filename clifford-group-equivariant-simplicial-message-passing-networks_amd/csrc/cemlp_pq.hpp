@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         PqA<NST> aT;                    // weight fragments of the next MIX phase, requested one ROW phase ahead
         {
             PQ_PHASE_IDS();
-            pq_load_a<NST>(aT, tabs + CF::ttoff(K, mL), lane, mp, mot, 2);
+            // (fragments loaded at their MIX phase: the prefetch cost registers at three waves per SIMD and bought nothing)
             float qs[2], dot[2], nl[2];
             static_for<0, 2>([&](auto mm) {
                 constexpr int mv = decltype(mm)::value;
@@ -1044,6 +1044,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             }
             f4 acc[4];
             pq_zero(acc);
+            pq_load_a<NST>(aT, tabs + CF::ttoff(K, mL), lane, mp, mot, 2);
             pq_mix_run<NST>(acc, bufB, aT, lane, mp);
             pq_wgrad(accL, bufB, bufA, wave, lane);
             __syncthreads();
@@ -1053,10 +1054,10 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         stamp(3);
         // ---- ROW: geometric product + normalisation backward -> gR -> B; gz stays in registers
         float gz[2][8];
-        PqCollect col[2];
+        PqCollect col;      // one buffer: a multivector's slots are flushed (16 at a time) before the next one starts
         {
             PQ_PHASE_IDS();
-            pq_load_a<NST>(aT, tabs + CF::ttoff(K, mR), lane, mp, mot, 2);
+            // (fragments loaded at their MIX phase: the prefetch cost registers at three waves per SIMD and bought nothing)
             static_for<0, 2>([&](auto mm) {
                 constexpr int mv = decltype(mm)::value;
                 const int c = cq + 16 * mv;
@@ -1082,7 +1083,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                     for (int t = 0; t < nd; ++t) R[d0 + t] *= invden[g];    // R holds r = R / den from here on
                 });
                 float (&rf)[8] = R;
-                pq_gp_bwd_z<ALG>(ggp[mv], z, rf, gz[mv], wrow, col[mv], small[mv], l16);
+                pq_gp_bwd_z<ALG>(ggp[mv], z, rf, gz[mv], wrow, col, small[mv], l16);
                 float gr[8];
 #pragma unroll
                 for (int d = 0; d < 8; ++d) gr[d] = 0.f;
@@ -1097,7 +1098,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                     });
                     gden *= invden[g];          // -sum gr R / den^2 with R = r den
                     const float sg = par[12 + g];
-                    col[mv].template add<CF::s_an + g>(gden * (nu[g] - 1.0f) * sg * (1.0f - sg), small[mv], l16);
+                    col.template add<CF::s_an + g>(gden * (nu[g] - 1.0f) * sg * (1.0f - sg), small[mv], l16);
                     const float inu = fast_rcp(nu[g]);
                     const float gq = (gden * sg) * (0.5f * qR[g]) * (inu * inu * inu);
                     static_for<0, nd>([&](auto t) {
@@ -1105,7 +1106,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                         gr[d] = __builtin_fmaf(gr[d], invden[g], (gq * den[g]) * (2.0f * qsf<ALG, d>) * rf[d]);
                     });
                 });
-                static_for<CF::s_an + G, 32>([&](auto ii) { col[mv].template add<decltype(ii)::value>(0.f, small[mv], l16); });
+                static_for<CF::s_an + G, 32>([&](auto ii) { col.template add<decltype(ii)::value>(0.f, small[mv], l16); });
                 pq_st8(bufB, r, c, gr);      // gR
                 pq_pin8(gz[mv]);
             });
@@ -1124,6 +1125,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             }
             f4 acc[4];
             pq_zero(acc);
+            pq_load_a<NST>(aT, tabs + CF::ttoff(K, mR), lane, mp, mot, 2);
             pq_mix_run<NST>(acc, bufB, aT, lane, mp);
             pq_wgrad(accR, bufB, bufA, wave, lane);
             __syncthreads();
@@ -1136,7 +1138,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
         f4 xa[NPRE], xb[K == 0 && MODE == MODE_EDGE ? NPRE : 1];
         {
             PQ_PHASE_IDS();
-            if constexpr (!(PLAIN && K == 0)) pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);     // W1^T: in front of the gathers
+            // (fragments loaded at their MIX phase: the prefetch cost registers at three waves per SIMD and bought nothing)
             int ia[NPRE], ib[NPRE];
 #pragma unroll
             for (int i = 0; i < NPRE; ++i) {
@@ -1204,8 +1206,8 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
 #pragma unroll
                     for (int t = 0; t < nd; ++t) ggate = __builtin_fmaf(g_[d0 + t], y[d0 + t], ggate);
                     const float gpre = ggate * gate * (1.0f - gate);
-                    col[mv].template add<CF::s_gate + 2 * g>(gpre * u, small[mv], l16);
-                    col[mv].template add<CF::s_gate + 2 * g + 1>(gpre, small[mv], l16);
+                    col.template add<CF::s_gate + 2 * g>(gpre * u, small[mv], l16);
+                    col.template add<CF::s_gate + 2 * g + 1>(gpre, small[mv], l16);
                     const float gu = gpre * par[4 + g];
                     static_for<0, nd>([&](auto t) {
                         constexpr int d = d0 + decltype(t)::value;
@@ -1215,10 +1217,10 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
                         g_[d] = live ? v : 0.f;     // gy
                     });
                 });
-                col[mv].template add<CF::s_b1>(g_[0], small[mv], l16);
-                col[mv].template add<CF::s_la>(g_la[mv], small[mv], l16);
-                col[mv].template add<CF::s_bL>(g_bL[mv], small[mv], l16);
-                static_for<CF::s_bL + 1, 48>([&](auto ii) { col[mv].template add<decltype(ii)::value>(0.f, small[mv], l16); });
+                col.template add<CF::s_b1>(g_[0], small[mv], l16);
+                col.template add<CF::s_la>(g_la[mv], small[mv], l16);
+                col.template add<CF::s_bL>(g_bL[mv], small[mv], l16);
+                static_for<CF::s_bL + 1, 48>([&](auto ii) { col.template add<decltype(ii)::value>(0.f, small[mv], l16); });
                 pq_st8(bufB, r, c, g_);
             });
 #pragma unroll
@@ -1235,6 +1237,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             PQ_PHASE_IDS();
             f4 acc[4];
             pq_zero(acc);
+            pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);
             pq_mix_run<NST>(acc, bufB, aT, lane, mp);
             pq_wgrad(accW0, bufB, bufA, wave, lane);
             f4 acca[4];
@@ -1299,6 +1302,7 @@ __global__ void __launch_bounds__(kPqThreads, PQ_BWD_WPE) cemlp_pq_bwd_kernel(co
             PQ_PHASE_IDS();
             f4 acch[4], accg[4];
             pq_zero(acch);
+            pq_load_a<NST>(aT, tabs + CF::ttoff(K, 0), lane, mp, mot, 2);
             pq_mix_run<NST>(acch, bufB, aT, lane, mp);
             pq_wgrad(accW0, bufB, bufA, wave, lane);
             pq_wgrad1(accW2, bufB, bufE, wave, lane);
