@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 PKG = "clifford-group-equivariant-simplicial-message-passing-networks_amd"
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: vector = matrix fp32 peak
 
 WORKLOADS = {
     # name: (metric, channels, nodes, edges per GPU)
@@ -491,6 +492,14 @@ def main():
             "layer_bytes_per_edge": round(bytes_per_edge, 1),
             "layer_frac_of_hbm_roofline": round(value / world * bytes_per_edge / (HBM_PEAK_GBS * 1e9), 5),
         }
+        # the second roofline: dense mixings D C (6C + A) MAC per edge (node program: D C (7C + T) per node), x 3
+        # with the backward; geometric product 2 C D^2 sign-table terms per row, x 4 with its backward; against MI355X's fp32 peak,
+        # ONE pool for vector and matrix instructions (tools/mfma_valu_overlap_probe.hip)
+        mac_edge = 3 * D * C * (6 * C + 6) + 4 * 2 * C * D * D
+        mac_node = 3 * D * C * (7 * C + 3) + 4 * 2 * C * D * D
+        mac_per_edge = mac_edge + (N / E_per) * mac_node
+        roofline["fp32_alu"] = {"mac_per_edge": round(mac_per_edge, 1), "peak_tflops": FP32_PEAK_TFLOPS,
+                                "layer_frac_of_fp32_peak": round(value / world * 2 * mac_per_edge / (FP32_PEAK_TFLOPS * 1e12), 5)}
         result = {
             "metric": "simplicial edges/sec (fwd+bwd) on Cl(3,0) 8-ch multivectors; % HBM roofline"
                       if args.workload == "S1" else f"simplicial edges/sec (fwd+bwd), workload {args.workload}",
