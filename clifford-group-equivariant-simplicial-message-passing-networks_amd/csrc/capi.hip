@@ -1291,7 +1291,8 @@ const char* csmpn_last_kernel(void) { return g_last_kernel; }
 /* diagnostic library only (`make stamps`, never shipped): device buffer of 25 uint64 per-phase cycle sums + wave count */
 void csmpn_debug_set_stamps(void* device_u64x25) { g_stamps = static_cast<unsigned long long*>(device_u64x25); }
 #endif
-int csmpn_abi_version(void) { return 2; }   // 2 (round 5): csmpn_embed_cemlp_* take n_vertex_rows, csmpn_cemlp_saved_floats takes flags
+int csmpn_abi_version(void) { return 2; }   // 2 (round 5): csmpn_embed_cemlp_* take n_vertex_rows, csmpn_cemlp_saved_floats takes flags;
+                                            // CSMPN_FLAG_WEIGHTS_PACKED has a meaning on the EGCL / CEMLP backward entry points, CSMPN_FLAG_SAVE_STATE on csmpn_cemlp_*
 const char* csmpn_build_target(void) { return "gfx950"; }
 
 int csmpn_metric_supported(const float* metric_host, int n) { return alg_id(metric_host, n) != ALG_NONE ? 1 : 0; }
