@@ -307,7 +307,7 @@ def test_egcl_golden_can_fail(pkg, golden_dir, name):
 
 
 def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_scale=None, slack=None, max_yard=None,
-                      attr_grad=False):
+                      attr_grad=False, rewire=None):
     """Seeded synthetic complex; HIP layer vs the float64 oracle with identical parameters.
 
     Indefinite metrics (Cl(4,1)) make the backward ill-conditioned on random inputs: the
@@ -321,6 +321,8 @@ def _oracle_egcl_case(metric, N, E, C, hidden, aggr, seed, residual=True, neg_sc
     oa = O.Algebra(metric, torch.float64)
     o32 = O.Algebra(metric, torch.float32)
     h, ei, ea, na = O.synthetic_complex(o32, N, E, C, seed=seed)
+    if rewire is not None:
+        ei = rewire(ei.clone())
     if neg_scale is not None:
         # well-conditioned inputs for an indefinite metric: blades containing a negative generator
         # are small, so the quadratic forms stay away from the null cone
@@ -396,6 +398,26 @@ def test_lane_kernel_shapes(pkg, metric, C, N, E, aggr, residual):
         # (tools/pg_err_compare.py) - another valid rounding of `agg`, ~1e2 amplification. Hence the atomic path's factor here too.
         with deterministic_aggregation():
             _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=N + E, residual=residual, neg_scale=0.02, attr_grad=True, slack=25.0)
+
+
+@pytest.mark.parametrize("metric,C", [((1.0, 1.0, 1.0), 32), ((1.0,) * 5, 28)], ids=["cl30-32", "cl50-28"])
+@pytest.mark.parametrize("aggr", ["mean", "sum"])
+def test_16_row_tile_families_hub_duplicates_isolated(pkg, metric, C, aggr):
+    """The 16-row-tile families (cemlp_pq.hpp, cemlp_pg.hpp) on an adjacency list that stresses their row I/O: three quarters
+    of the edges end in ONE node (whole tiles with a single target: the scatter sums them before its one atomic; in-degree
+    3 000 under aggr = mean), exact duplicates, self loops, nodes without any edge, a row count that is a multiple of 16
+    (no tail tile) - against the float64 oracle with attribute gradients."""
+    N, E = 97, 4096
+
+    def rewire(ei):
+        ei[1, : 3 * E // 4] = 7                      # the hub
+        ei[:, -16:] = ei[:, :16]                     # duplicates
+        ei[0, 100:110] = ei[1, 100:110]              # self loops
+        keep = (ei != 90) & (ei != 91)               # two isolated nodes
+        ei[~keep] = 3
+        return ei
+
+    _oracle_egcl_case(list(metric), N, E, C, C, aggr, seed=77, attr_grad=True, rewire=rewire)
 
 
 def test_channel_mfma_backward_dispatched(pkg):
