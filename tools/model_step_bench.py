@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--points", type=int, default=8)
-    ap.add_argument("--model", default="hulls", choices=["hulls", "md17", "motion"])
+    ap.add_argument("--model", default="hulls", choices=["hulls", "md17", "motion", "nba"])
     ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(foreach) instead of fused=True")
     ap.add_argument("--no-fused-grads", action="store_true", help="hand parameter gradients to autograd (one add kernel per tensor)")
     ap.add_argument("--profile-ops", action="store_true", help="torch.profiler over 3 eager steps: the small GPU kernels by Python call site")
@@ -120,6 +120,25 @@ def main():
         batch._names.append("y")
         batch = batch.to(dev)
         features = ["pos", "vel", "y"]
+    elif args.model == "nba":
+        # NBA-shaped batch (nba_cssmpnn.py:12-190: Cl(2,0), 40 channels, 4 layers, aggr = sum): 6 agents in the plane (5 players +
+        # the ball), 10 frames, Vietoris-Rips complex of the first frame; the target: 40 future frames of the 5 players
+        V, F, graphs, ys = 6, 10, [], []
+        for _ in range(args.batch):
+            base = rng.standard_normal((V, 2)).astype(np.float32)
+            c = cx.rips_complex(base, dis=1.6, max_dim=2)
+            S = c.n_simplices
+            pos, vel = torch.zeros(S, F, 2), torch.zeros(S, F, 2)
+            pos[:V] = torch.from_numpy(base)[:, None, :] + 0.05 * torch.from_numpy(rng.standard_normal((V, F, 2)).astype(np.float32))
+            vel[:V] = 0.1 * torch.from_numpy(rng.standard_normal((V, F, 2)).astype(np.float32))
+            c.features.update(pos=pos, vel=vel)
+            graphs.append(c)
+            ys.append(torch.from_numpy(rng.standard_normal((V - 1, 4 * F, 2)).astype(np.float32)))
+        batch = cx.collate(graphs)
+        batch.y = torch.cat(ys, dim=0)
+        batch._names.append("y")
+        batch = batch.to(dev)
+        features = ["pos", "vel", "y"]
     else:
         # MD17-shaped batch (md17_cssmpnn.py; csmpn/configs/md17.yaml: Cl(3,0), 32 channels, 5 layers): 21 atoms
         # (aspirin), 10 frames, Vietoris-Rips complex of the first frame, random positions / velocities / charges
@@ -140,7 +159,8 @@ def main():
         batch = batch.to(dev)
         features = ["loc", "vel", "charges", "y"]
     torch.manual_seed(0)
-    model = {"hulls": M.HullsSimplicialMPNN, "md17": M.MD17SimplicialMPNN, "motion": M.MotionSimplicialMPNN}[args.model]().to(dev)
+    model = {"hulls": M.HullsSimplicialMPNN, "md17": M.MD17SimplicialMPNN, "motion": M.MotionSimplicialMPNN,
+             "nba": M.NBASimplicialMPNN}[args.model]().to(dev)
     # the reference trains with torch.optim.Adam (csmpn/configs/hulls.yaml); fused=True is the same update in one
     # multi-tensor kernel (the default foreach path with capturable=True issues ~300 per-tensor div kernels: 1.5 ms)
     from csmpn_hip.graphed import flatten_parameters
@@ -186,7 +206,7 @@ def main():
     torch.cuda.synchronize()
     graph_ms = (time.perf_counter() - t0) * 1e3 / args.steps
     label = {"hulls": "hulls (Cl(5,0), 28 channels, 3 layers)", "md17": "md17 (Cl(3,0), 32 channels, 5 layers)",
-             "motion": "motion (Cl(3,0), 16 channels, 4 layers)"}[args.model]
+             "motion": "motion (Cl(3,0), 16 channels, 4 layers)", "nba": "nba (Cl(2,0), 40 channels, 4 layers)"}[args.model]
     print(json.dumps({"model": label, "graphs_per_batch": args.batch,
                       "simplices": int(batch.x_ind.shape[0]), "adjacencies": int(batch.edge_index.shape[1]),
                       "fused_grad_accumulation": not args.no_fused_grads, "fused_adam": not args.no_fused_adam, "flat_parameters": not args.no_flat_params, "eager_ms_per_step": round(eager_ms, 3), "graphed_ms_per_step": round(graph_ms, 3),
