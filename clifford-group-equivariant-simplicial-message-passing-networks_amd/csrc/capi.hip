@@ -645,7 +645,6 @@ unsigned long long* g_stamps = nullptr;   // diagnostic builds: device buffer of
 // reserved at the END of the workspace; 0 when the shape is not served by those kernels
 bool cm_bwd_enabled();
 // 16-row-tile MFMA-mixing kernels for Cl(3,0) (cemlp_pq.hpp): weight-fragment tables + one gradient slice per workgroup
-constexpr unsigned kPqGridCap = 768;   // three 4-wave workgroups per CU
 size_t pq_region_bytes(int nblk, int ch, int i0) {
     size_t best = 0;
     for (int mode : {MODE_EDGE, MODE_NODE, MODE_PLAIN}) {

@@ -6,6 +6,7 @@
 namespace csmpn {
 namespace {
 using ALG_T = Alg<3, 0u>;
+static_assert(kPqMaxGroups == (int)kPqGridCap, "slice regions are sized for the grid cap (capi.hip: pq_region_bytes)");
 
 template <int MODE, int NA, int NBLK>
 hipError_t pq_launch(bool bwd, bool pack, unsigned grid, hipStream_t st, const DevCemlp& Cd, const RowIO& io_in, float* tabs) {

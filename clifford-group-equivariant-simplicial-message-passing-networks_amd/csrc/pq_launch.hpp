@@ -5,6 +5,8 @@
 #include "cemlp_device.hpp"
 
 namespace csmpn {
+// workgroups a launch may have = gradient slices the workspace region holds (three 4-wave workgroups per CU)
+constexpr unsigned kPqGridCap = 768;
 // floats of the weight-fragment tables / of one workgroup's gradient slices (all blocks: each block's launch has its own region) for
 // (mode, blocks, channels, attribute channels - MODE_PLAIN: input channels of block 0); 0: shape not served
 size_t cemlp_pq_table_floats_n3(int mode, int nblk, int channels, int attr);
