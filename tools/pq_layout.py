@@ -71,11 +71,12 @@ def run(CS,f):
 fs={'0':lambda r:0,'b0':lambda r:r&1,'b1':lambda r:(r>>1)&1,'b2':lambda r:(r>>2)&1,'b3':lambda r:(r>>3)&1,
     'b0^b2':lambda r:(r^(r>>2))&1,'b1^b2':lambda r:((r>>1)^(r>>2))&1,'b2^b3':lambda r:((r>>2)^(r>>3))&1,'b0^b3':lambda r:(r^(r>>3))&1,'b1^b3':lambda r:((r>>1)^(r>>3))&1,
     'b0^b1':lambda r:(r^(r>>1))&1,'par':lambda r:bin(r).count('1')&1}
-out=[]
-for CS in range(128,200,4):
-    for name,f in fs.items():
-        r=run(CS,f)
-        score=(r['A']-4)*4+(r['E']-4)*3+(r['G']-4)+(r['H']-2)+max(0,r['Cw']-13)+max(0,r['Dw']-13)+max(0,r['Fw']-13)
-        out.append((score,CS,name,r))
-out.sort(key=lambda t:(t[0],t[1]))
-for o in out[:15]: print(o)
+if __name__ == "__main__":
+    out=[]
+    for CS in range(128,200,4):
+        for name,f in fs.items():
+            r=run(CS,f)
+            score=(r['A']-4)*4+(r['E']-4)*3+(r['G']-4)+(r['H']-2)+max(0,r['Cw']-13)+max(0,r['Dw']-13)+max(0,r['Fw']-13)
+            out.append((score,CS,name,r))
+    out.sort(key=lambda t:(t[0],t[1]))
+    for o in out[:15]: print(o)
